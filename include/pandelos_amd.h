@@ -1,0 +1,156 @@
+/*
+ * pandelos_amd.h — C ABI of the MI355X-native PanDelos hot path
+ * (k-mer dictionary matching + all-vs-all gene similarity scoring).
+ *
+ * This is the drop-in boundary.  In the reference the same boundary is the JNI pair
+ *     Java_infoasys_cli_pangenes_PangeneNative_preprocessSequences   ig/native/pangene_native.h:16-17
+ *     Java_infoasys_cli_pangenes_PangeneNative_computeScores         ig/native/pangene_native.h:24-25
+ * implemented by ig/native/library.cpp:189-371 and :529-604 and declared on the Java side at
+ * ig/infoasys/cli/pangenes/PangeneNative.java:14-15.  libnative.so (this project's JNI shim,
+ * include/pdl_jni_abi.h + pandelos_amd/csrc/jni_shim.cpp) exports those two symbols and forwards
+ * to the functions below; any other host (the Python mirror in pandelos_amd/, the C++ driver, a cgo /
+ * N-API / ctypes stub) binds the functions below directly.
+ *
+ * Plain C: pointers and sizes only.  All work runs on one HIP device (gfx950); there is no CPU
+ * fallback — pdl_create fails when no device is usable.
+ */
+#ifndef PANDELOS_AMD_H
+#define PANDELOS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDL_API __attribute__((visibility("default")))
+
+typedef struct pdl_ctx pdl_ctx;
+
+enum {
+    PDL_OK = 0,
+    PDL_ERR_KVALUE = -1,       /* k <= 0: the reference prints "K value must be greater than 0." and exit(1)s (library.cpp:90-93) */
+    PDL_ERR_EMPTY = -2,        /* no k-mer at all: undefined behaviour in the reference (library.cpp:297) */
+    PDL_ERR_ARGUMENT = -3,     /* NULL pointer, genome id out of range, ... */
+    PDL_ERR_DEVICE = -4,       /* a HIP call failed; see pdl_last_error */
+    PDL_ERR_STATE = -5,        /* compute before preprocess, etc. */
+    PDL_ERR_UNSUPPORTED = -6   /* input outside the implemented domain (stated in the message) */
+};
+
+typedef struct {
+    int32_t device;            /* HIP device ordinal; -1 = current device */
+    void *stream;              /* hipStream_t to run on; NULL = a stream owned by the context */
+    uint32_t flags;            /* PDL_FLAG_* */
+    uint32_t reserved;
+} pdl_config;
+
+#define PDL_FLAG_CANONICAL_ORDER 1u  /* emit each row's cells by ascending column instead of the reference's
+                                        first-touch order (library.cpp:456-482,493); cheaper, same cell set */
+
+/* What preprocessSequences prints as its cost model (library.cpp:337-350) plus the sizes every
+ * run must report for the roofline (R, M, U, P). */
+typedef struct {
+    uint64_t residues;          /* R */
+    uint64_t kmer_occurrences;  /* M  = sum over genes of max(len-k+1, 0) */
+    uint64_t dictionary_records;/* U  = unique (rank, gene) records (library.cpp:280-287) */
+    uint64_t shared_records;    /* U' = records in rank-groups with >= 2 records (= posting ranges, library.cpp:318-326) */
+    uint64_t groups;            /* rank-groups with >= 2 records */
+    uint64_t total_cost;        /* P  = "Total cost: P lookups" (library.cpp:327,349) */
+    float linear_ratio;         /* P / sum kseq_lengths (library.cpp:350) */
+    uint32_t sequences;         /* N */
+    uint32_t genomes;           /* G */
+    uint32_t rank_base;         /* alphabet size B (library.cpp:96-100) */
+    uint32_t rank_bits;         /* bits needed for a rank (64 in hash mode) */
+    int32_t hash_fallback;      /* 1 when B^k overflows 64 bits (library.cpp:103-119) */
+    int32_t kvalue;
+} pdl_cost;
+
+/* Flat mirror of ig/infoasys/cli/pangenes/Scores.java:4-34 exactly as library.cpp:542-603 fills it.
+ * All arrays are host memory owned by the library until pdl_free_scores. */
+typedef struct {
+    uint32_t scoresCount;
+    uint32_t rows;                 /* genes of this genome = first dimension of max_genome_score */
+    uint32_t genomes;              /* G = second dimension of max_genome_score */
+    uint32_t sequences;            /* N = length of max_genome_score_col and scoresMaxMappings */
+    float *scores;                 /* [scoresCount] */
+    float *percs;                  /* [scoresCount] */
+    float *tr_percs;               /* [scoresCount] */
+    int32_t *row;                  /* [scoresCount] */
+    int32_t *column;               /* [scoresCount] */
+    int32_t *first_seq_genome;     /* [scoresCount] */
+    int32_t *second_seq_genome;    /* [scoresCount] */
+    float *max_genome_score;       /* [rows][genomes] row-major (Java float[][]) */
+    float *max_genome_score_col;   /* [sequences] */
+    int32_t *scoresMaxMappings;    /* [sequences]; INT32_MAX for genes of other genomes (library.cpp:428-432) */
+} pdl_scores;
+
+/* Device time of the stages of the last preprocess / score pass, from HIP events on the context's
+ * stream (milliseconds), and the counters the roofline needs. */
+typedef struct {
+    float hist_ms, rank_ms, sort_rank_ms, dict_ms, sort_seq_ms, ranges_ms;  /* preprocess */
+    float join_ms, join_overflow_ms, order_ms;                             /* scoring */
+    float preprocess_total_ms, score_total_ms;
+    uint64_t emitted_cells;        /* Z over the genomes scored by this context */
+    uint64_t scored_rows;          /* rows (genes) scored by this context */
+    uint64_t scored_lookups;       /* P restricted to those rows */
+    uint64_t overflow_rows;        /* rows that left the LDS table for the HBM table */
+    uint32_t join_launches;
+    uint32_t reserved;
+} pdl_timings;
+
+PDL_API pdl_ctx *pdl_create(const pdl_config *cfg /* may be NULL */);
+PDL_API void pdl_destroy(pdl_ctx *);
+/* Message of the last failure on this context (or of pdl_create when ctx == NULL); never NULL. */
+PDL_API const char *pdl_last_error(const pdl_ctx *);
+
+/* preprocessSequences (library.cpp:189-371).  Gene i is residues[offsets[i] .. offsets[i+1]), one byte
+ * per character (the reference reads UTF-16 units and is only defined for units < 256, library.cpp:76,223);
+ * genome_of[i] is its dense genome id in first-seen order (PangeneIData.java:56-62).  Resets the context
+ * (library.cpp:192).  only_complexity != 0 stops after the cost model (PangeneNative.java:10-12).
+ * The _host form takes host pointers and copies them to the device; the _device form takes device
+ * pointers that must stay valid until the next preprocess or destroy. */
+PDL_API int pdl_preprocess(pdl_ctx *, const uint8_t *residues, const uint64_t *offsets,
+                           const uint32_t *genome_of, uint32_t n_sequences, int kvalue,
+                           int only_complexity, pdl_cost *out_cost /* may be NULL */);
+PDL_API int pdl_preprocess_device(pdl_ctx *, const uint8_t *d_residues, const uint64_t *d_offsets,
+                                  const uint32_t *d_genome_of, uint32_t n_sequences, uint64_t n_residues,
+                                  int kvalue, int only_complexity, pdl_cost *out_cost);
+
+/* "Genome g cost = ..." (library.cpp:535-538) */
+PDL_API int pdl_genome_cost(const pdl_ctx *, uint32_t genome, uint64_t *out_cost);
+/* Per-gene cost (computation_costs[].total_visited, library.cpp:327) and k-mer count (kseq_lengths, :250-262) */
+PDL_API int pdl_sequence_costs(const pdl_ctx *, uint64_t *out_total_visited /* [N] */, uint32_t *out_kseq_lengths /* [N], may be NULL */);
+
+/* Restrict the genomes this context scores (multi-GPU sharding: one context per GPU, each with the
+ * full dictionary and a disjoint genome list).  Default: all genomes.  Must precede pdl_score_all. */
+PDL_API int pdl_set_genome_shard(pdl_ctx *, const uint32_t *genomes, uint32_t count);
+
+/* computeScores for every genome of the shard in one device pass (library.cpp:409-527 for each
+ * genome); results stay in HBM.  Idempotent until the next preprocess. */
+PDL_API int pdl_score_all(pdl_ctx *);
+
+/* computeScores + the marshalling of library.cpp:542-603 for one genome: runs pdl_score_all on first
+ * use, then copies that genome's block to the host.  Re-entrant from several host threads, like the
+ * reference (Pangenes.java:54-66). */
+PDL_API int pdl_compute_scores(pdl_ctx *, uint32_t genome, pdl_scores *out);
+PDL_API void pdl_free_scores(pdl_scores *);
+
+/* Number of emitted cells per genome after pdl_score_all ([G], 0 for genomes outside the shard) */
+PDL_API int pdl_scores_counts(pdl_ctx *, uint32_t *out_counts);
+
+/* Parity-test introspection: the dictionary in (rank, gene) order as library.cpp:270-287 leaves it
+ * (before the group scan's re-sort of the folded last group).  Arrays sized by pdl_cost.dictionary_records. */
+PDL_API int pdl_get_dictionary(pdl_ctx *, uint64_t *ranks, uint32_t *seqs, uint32_t *counts);
+/* Alphabet rank table (library.cpp:96-99) and B^(k-1) (library.cpp:101-119) */
+PDL_API int pdl_get_rank_table(const pdl_ctx *, uint8_t out_rank_values[256], uint64_t *out_last_multiplier);
+
+PDL_API int pdl_get_timings(pdl_ctx *, pdl_timings *out);
+
+/* Library/build identification, e.g. "pandelos_amd 0.1 gfx950" */
+PDL_API const char *pdl_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PANDELOS_AMD_H */

@@ -1,0 +1,302 @@
+// pdl_api.hip — the C ABI of include/pandelos_amd.h over the two device stages
+// (pdl_dict.hip: preprocessSequences; pdl_join.hip: computeScores).
+#include "pdl_common.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+
+static thread_local std::string g_create_error = "";
+
+#define PDL_GUARD_BEGIN try {
+#define PDL_GUARD_END(ctx_)                                                       \
+    } catch (const pdl_error &e) {                                                \
+        if (ctx_) (ctx_)->err = e.msg; else g_create_error = e.msg;               \
+        return e.code;                                                            \
+    } catch (const std::bad_alloc &) {                                            \
+        if (ctx_) (ctx_)->err = "host allocation failed";                         \
+        return PDL_ERR_DEVICE;                                                    \
+    }
+
+template <class T> static T *xalloc(size_t n) {
+    T *p = static_cast<T *>(malloc((n ? n : 1) * sizeof(T)));
+    if (!p) throw std::bad_alloc();
+    return p;
+}
+
+extern "C" {
+
+const char *pdl_version(void) { return "pandelos_amd 0.1 (HIP, gfx950)"; }
+
+pdl_ctx *pdl_create(const pdl_config *cfg) {
+    pdl_ctx *c = nullptr;
+    try {
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev == 0)
+            PDL_FAIL(PDL_ERR_DEVICE, "no HIP device available (%s): pandelos_amd has no CPU path", hipGetErrorString(e));
+        c = new pdl_ctx();
+        int dev = cfg ? cfg->device : -1;
+        if (dev < 0) PDL_HIP(hipGetDevice(&dev));
+        if (dev >= ndev) PDL_FAIL(PDL_ERR_ARGUMENT, "device %d out of range (%d devices)", dev, ndev);
+        c->device = dev;
+        PDL_HIP(hipSetDevice(dev));
+        c->flags = cfg ? cfg->flags : 0;
+        if (cfg && cfg->stream) { c->stream = (hipStream_t) cfg->stream; c->own_stream = false; }
+        else { PDL_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+        return c;
+    } catch (const pdl_error &e) {
+        g_create_error = e.msg;
+        delete c;
+        return nullptr;
+    }
+}
+
+void pdl_destroy(pdl_ctx *c) {
+    if (!c) return;
+    (void) hipSetDevice(c->device);
+    (void) hipStreamSynchronize(c->stream);
+    for (auto &e : c->ev) { if (e.a) (void) hipEventDestroy(e.a); if (e.b) (void) hipEventDestroy(e.b); }
+    if (c->own_stream && c->stream) (void) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *pdl_last_error(const pdl_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+static void fill_cost(const pdl_ctx *c, pdl_cost *out) {
+    if (!out) return;
+    memset(out, 0, sizeof(*out));
+    out->residues = c->R; out->kmer_occurrences = c->M; out->dictionary_records = c->U;
+    out->shared_records = c->Ushared; out->groups = c->NG; out->total_cost = c->P;
+    out->linear_ratio = c->sum_kseq ? (float) c->P / (float) c->sum_kseq : 0.f;   // library.cpp:350
+    out->sequences = c->N; out->genomes = c->G; out->rank_base = c->rp.base; out->rank_bits = c->rp.rank_bits;
+    out->hash_fallback = (int32_t) c->rp.hash_fallback; out->kvalue = (int32_t) c->rp.k;
+}
+
+// genome layout on the host: genome_sequences (library.cpp:244,268) as CSR
+static void build_genome_layout(pdl_ctx *c) {
+    const uint32_t N = c->N;
+    uint32_t G = 0;
+    for (uint32_t i = 0; i < N; i++) G = std::max(G, c->h_genome_of[i] + 1);      // library.cpp:242
+    if ((uint64_t) G > (uint64_t) N) PDL_FAIL(PDL_ERR_ARGUMENT, "genome ids are not dense: max id %u with %u genes", G - 1, N);
+    c->G = G;
+    c->h_genome_row_off.assign((size_t) G + 1, 0);
+    for (uint32_t i = 0; i < N; i++) c->h_genome_row_off[c->h_genome_of[i] + 1]++;
+    for (uint32_t g = 0; g < G; g++) c->h_genome_row_off[g + 1] += c->h_genome_row_off[g];
+    c->h_genome_rows.resize(N);
+    std::vector<uint32_t> cur(c->h_genome_row_off.begin(), c->h_genome_row_off.end() - 1);
+    for (uint32_t i = 0; i < N; i++) c->h_genome_rows[cur[c->h_genome_of[i]]++] = i;
+}
+
+static int preprocess_common(pdl_ctx *c, uint32_t n, uint64_t n_res, int k, int only_complexity, pdl_cost *out_cost) {
+    PDL_GUARD_BEGIN
+    PDL_HIP(hipSetDevice(c->device));
+    c->preprocessed = false; c->scored = false; c->shard_set = false; c->shard.clear();
+    c->N = n; c->R = n_res;
+    c->U = c->Ushared = c->NG = c->P = c->M = 0;
+    if (k <= 0) PDL_FAIL(PDL_ERR_KVALUE, "K value must be greater than 0.");
+    if (n == 0) PDL_FAIL(PDL_ERR_EMPTY, "empty dataset");
+    build_genome_layout(c);
+    pdl_run_preprocess(c, k, only_complexity != 0);
+    c->preprocessed = true;
+    fill_cost(c, out_cost);
+    return PDL_OK;
+    PDL_GUARD_END(c)
+}
+
+int pdl_preprocess(pdl_ctx *c, const uint8_t *residues, const uint64_t *offsets, const uint32_t *genome_of,
+                   uint32_t n, int k, int only_complexity, pdl_cost *out_cost) {
+    if (!c) return PDL_ERR_ARGUMENT;
+    std::lock_guard<std::mutex> lk(c->mu);
+    PDL_GUARD_BEGIN
+    if (!offsets || !genome_of || (!residues && n && offsets[n] > 0)) PDL_FAIL(PDL_ERR_ARGUMENT, "null input pointer");
+    PDL_HIP(hipSetDevice(c->device));
+    const uint64_t n_res = n ? offsets[n] - offsets[0] : 0;
+    if (n && offsets[0] != 0) PDL_FAIL(PDL_ERR_ARGUMENT, "offsets[0] must be 0");
+    c->in_res.alloc(n_res + 16); c->in_off.alloc(((size_t) n + 1) * 8); c->in_gen.alloc((size_t) n * 4 + 4);
+    if (n_res) PDL_HIP(hipMemcpyAsync(c->in_res.p, residues, n_res, hipMemcpyHostToDevice, c->stream));
+    PDL_HIP(hipMemcpyAsync(c->in_off.p, offsets, ((size_t) n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    if (n) PDL_HIP(hipMemcpyAsync(c->in_gen.p, genome_of, (size_t) n * 4, hipMemcpyHostToDevice, c->stream));
+    c->d_res = c->in_res.as<uint8_t>(); c->d_off = c->in_off.as<uint64_t>(); c->d_gen = c->in_gen.as<uint32_t>();
+    c->h_genome_of.assign(genome_of, genome_of + n);
+    PDL_HIP(hipStreamSynchronize(c->stream));
+    PDL_GUARD_END(c)
+    return preprocess_common(c, n, n ? offsets[n] : 0, k, only_complexity, out_cost);
+}
+
+int pdl_preprocess_device(pdl_ctx *c, const uint8_t *d_residues, const uint64_t *d_offsets, const uint32_t *d_genome_of,
+                          uint32_t n, uint64_t n_res, int k, int only_complexity, pdl_cost *out_cost) {
+    if (!c) return PDL_ERR_ARGUMENT;
+    std::lock_guard<std::mutex> lk(c->mu);
+    PDL_GUARD_BEGIN
+    if (!d_offsets || !d_genome_of || (!d_residues && n_res)) PDL_FAIL(PDL_ERR_ARGUMENT, "null input pointer");
+    if (((uintptr_t) d_residues & 15) != 0) PDL_FAIL(PDL_ERR_ARGUMENT, "d_residues must be 16-byte aligned");
+    PDL_HIP(hipSetDevice(c->device));
+    c->d_res = d_residues; c->d_off = d_offsets; c->d_gen = d_genome_of;
+    c->h_genome_of.resize(n);
+    if (n) PDL_HIP(hipMemcpyAsync(c->h_genome_of.data(), d_genome_of, (size_t) n * 4, hipMemcpyDeviceToHost, c->stream));
+    PDL_HIP(hipStreamSynchronize(c->stream));
+    PDL_GUARD_END(c)
+    return preprocess_common(c, n, n_res, k, only_complexity, out_cost);
+}
+
+int pdl_genome_cost(const pdl_ctx *c, uint32_t genome, uint64_t *out) {
+    if (!c || !out) return PDL_ERR_ARGUMENT;
+    if (!c->preprocessed) return PDL_ERR_STATE;
+    if (genome >= c->G) return PDL_ERR_ARGUMENT;
+    *out = c->h_genome_cost[genome];
+    return PDL_OK;
+}
+
+int pdl_sequence_costs(const pdl_ctx *cc, uint64_t *out_cost, uint32_t *out_kseq) {
+    pdl_ctx *c = const_cast<pdl_ctx *>(cc);
+    if (!c || !out_cost) return PDL_ERR_ARGUMENT;
+    if (!c->preprocessed) return PDL_ERR_STATE;
+    std::lock_guard<std::mutex> lk(c->mu);
+    PDL_GUARD_BEGIN
+    PDL_HIP(hipSetDevice(c->device));
+    PDL_HIP(hipMemcpyAsync(out_cost, c->cost.p, (size_t) c->N * 8, hipMemcpyDeviceToHost, c->stream));
+    if (out_kseq) PDL_HIP(hipMemcpyAsync(out_kseq, c->kseq_len.p, (size_t) c->N * 4, hipMemcpyDeviceToHost, c->stream));
+    PDL_HIP(hipStreamSynchronize(c->stream));
+    return PDL_OK;
+    PDL_GUARD_END(c)
+}
+
+int pdl_set_genome_shard(pdl_ctx *c, const uint32_t *genomes, uint32_t count) {
+    if (!c || (!genomes && count)) return PDL_ERR_ARGUMENT;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->preprocessed) { c->err = "pdl_set_genome_shard before pdl_preprocess"; return PDL_ERR_STATE; }
+    std::vector<uint32_t> s(genomes, genomes + count);
+    std::sort(s.begin(), s.end());
+    for (size_t i = 0; i < s.size(); i++) {
+        if (s[i] >= c->G || (i && s[i] == s[i - 1])) { c->err = "genome shard: id out of range or repeated"; return PDL_ERR_ARGUMENT; }
+    }
+    c->shard = std::move(s);
+    c->shard_set = true;
+    c->scored = false;
+    return PDL_OK;
+}
+
+static int score_all_locked(pdl_ctx *c) {
+    PDL_GUARD_BEGIN
+    if (!c->preprocessed) PDL_FAIL(PDL_ERR_STATE, "pdl_score_all before pdl_preprocess");
+    if (c->only_complexity) PDL_FAIL(PDL_ERR_STATE, "the dictionary was built in complexity-only mode (no posting ranges)");
+    if (c->scored) return PDL_OK;
+    PDL_HIP(hipSetDevice(c->device));
+    pdl_run_score_all(c);
+    return PDL_OK;
+    PDL_GUARD_END(c)
+}
+
+int pdl_score_all(pdl_ctx *c) {
+    if (!c) return PDL_ERR_ARGUMENT;
+    std::lock_guard<std::mutex> lk(c->mu);
+    return score_all_locked(c);
+}
+
+int pdl_scores_counts(pdl_ctx *c, uint32_t *out) {
+    if (!c || !out) return PDL_ERR_ARGUMENT;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int rc = score_all_locked(c);
+    if (rc != PDL_OK) return rc;
+    for (uint32_t g = 0; g < c->G; g++) {
+        int32_t lg = c->h_local_genome[g];
+        out[g] = lg < 0 ? 0u : (uint32_t) (c->h_cell_off[lg + 1] - c->h_cell_off[lg]);
+    }
+    return PDL_OK;
+}
+
+void pdl_free_scores(pdl_scores *s) {
+    if (!s) return;
+    free(s->scores); free(s->percs); free(s->tr_percs); free(s->row); free(s->column);
+    free(s->first_seq_genome); free(s->second_seq_genome); free(s->max_genome_score);
+    free(s->max_genome_score_col); free(s->scoresMaxMappings);
+    memset(s, 0, sizeof(*s));
+}
+
+int pdl_compute_scores(pdl_ctx *c, uint32_t genome, pdl_scores *out) {
+    if (!c || !out) return PDL_ERR_ARGUMENT;
+    memset(out, 0, sizeof(*out));
+    std::lock_guard<std::mutex> lk(c->mu);     // device copies are serialised; host threads may call concurrently
+    int rc = score_all_locked(c);
+    if (rc != PDL_OK) return rc;
+    PDL_GUARD_BEGIN
+    if (genome >= c->G) PDL_FAIL(PDL_ERR_ARGUMENT, "genome %u out of range (%u genomes)", genome, c->G);
+    const int32_t lg = c->h_local_genome[genome];
+    if (lg < 0) PDL_FAIL(PDL_ERR_ARGUMENT, "genome %u is not in this context's shard", genome);
+    PDL_HIP(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const uint32_t N = c->N, G = c->G;
+    const uint64_t z0 = c->h_cell_off[lg], z1 = c->h_cell_off[lg + 1];
+    const uint32_t z = (uint32_t) (z1 - z0);
+    const uint32_t p0 = c->h_task_row_off[lg], rows = c->h_task_row_off[lg + 1] - p0;
+    out->scoresCount = z; out->rows = rows; out->genomes = G; out->sequences = N;
+    out->scores = xalloc<float>(z); out->percs = xalloc<float>(z); out->tr_percs = xalloc<float>(z);
+    out->row = xalloc<int32_t>(z); out->column = xalloc<int32_t>(z);
+    out->first_seq_genome = xalloc<int32_t>(z); out->second_seq_genome = xalloc<int32_t>(z);
+    out->max_genome_score = xalloc<float>((size_t) rows * G);
+    out->max_genome_score_col = xalloc<float>(N);
+    out->scoresMaxMappings = xalloc<int32_t>(N);
+    if (z) {
+        PDL_HIP(hipMemcpyAsync(out->scores, c->c_score.as<float>() + z0, (size_t) z * 4, hipMemcpyDeviceToHost, st));
+        PDL_HIP(hipMemcpyAsync(out->percs, c->c_perc.as<float>() + z0, (size_t) z * 4, hipMemcpyDeviceToHost, st));
+        PDL_HIP(hipMemcpyAsync(out->tr_percs, c->c_tr.as<float>() + z0, (size_t) z * 4, hipMemcpyDeviceToHost, st));
+        PDL_HIP(hipMemcpyAsync(out->row, c->c_row.as<int32_t>() + z0, (size_t) z * 4, hipMemcpyDeviceToHost, st));
+        PDL_HIP(hipMemcpyAsync(out->column, c->c_col.as<int32_t>() + z0, (size_t) z * 4, hipMemcpyDeviceToHost, st));
+    }
+    if (rows) PDL_HIP(hipMemcpyAsync(out->max_genome_score, c->MS.as<float>() + (size_t) p0 * G, (size_t) rows * G * 4, hipMemcpyDeviceToHost, st));
+    PDL_HIP(hipMemcpyAsync(out->max_genome_score_col, c->CM.as<float>() + (size_t) lg * N, (size_t) N * 4, hipMemcpyDeviceToHost, st));
+    PDL_HIP(hipStreamSynchronize(st));
+    // library.cpp:571-575: genome of row / column per cell;  :428-432: flat map
+    for (uint32_t i = 0; i < z; i++) {
+        out->first_seq_genome[i] = (int32_t) c->h_genome_of[out->row[i]];
+        out->second_seq_genome[i] = (int32_t) c->h_genome_of[out->column[i]];
+    }
+    for (uint32_t i = 0; i < N; i++) out->scoresMaxMappings[i] = std::numeric_limits<int32_t>::max();
+    for (uint32_t j = 0; j < rows; j++) out->scoresMaxMappings[c->h_genome_rows[c->h_genome_row_off[genome] + j]] = (int32_t) j;
+    return PDL_OK;
+    } catch (const pdl_error &e) { c->err = e.msg; pdl_free_scores(out); return e.code;
+    } catch (const std::bad_alloc &) { c->err = "host allocation failed"; pdl_free_scores(out); return PDL_ERR_DEVICE; }
+}
+
+int pdl_get_dictionary(pdl_ctx *c, uint64_t *ranks, uint32_t *seqs, uint32_t *counts) {
+    if (!c) return PDL_ERR_ARGUMENT;
+    std::lock_guard<std::mutex> lk(c->mu);
+    PDL_GUARD_BEGIN
+    if (!c->preprocessed) PDL_FAIL(PDL_ERR_STATE, "pdl_get_dictionary before pdl_preprocess");
+    PDL_HIP(hipSetDevice(c->device));
+    const uint64_t U = c->U, M = c->M;
+    std::vector<uint32_t> recpos(U);
+    std::vector<uint2> post(U);
+    PDL_HIP(hipMemcpyAsync(recpos.data(), c->recpos.p, U * 4, hipMemcpyDeviceToHost, c->stream));
+    PDL_HIP(hipMemcpyAsync(post.data(), c->post.p, U * 8, hipMemcpyDeviceToHost, c->stream));
+    std::vector<uint8_t> keys(M * (c->key64 ? 8 : 4));
+    PDL_HIP(hipMemcpyAsync(keys.data(), c->keys_b.p, keys.size(), hipMemcpyDeviceToHost, c->stream));
+    PDL_HIP(hipStreamSynchronize(c->stream));
+    for (uint64_t u = 0; u < U; u++) {
+        if (ranks) ranks[u] = c->key64 ? reinterpret_cast<uint64_t *>(keys.data())[recpos[u]]
+                                       : (uint64_t) reinterpret_cast<uint32_t *>(keys.data())[recpos[u]];
+        if (seqs) seqs[u] = post[u].x;
+        if (counts) counts[u] = post[u].y;
+    }
+    return PDL_OK;
+    PDL_GUARD_END(c)
+}
+
+int pdl_get_rank_table(const pdl_ctx *c, uint8_t out[256], uint64_t *out_lm) {
+    if (!c || !out) return PDL_ERR_ARGUMENT;
+    if (!c->preprocessed) return PDL_ERR_STATE;
+    memcpy(out, c->rp.rank_values, 256);
+    if (out_lm) *out_lm = c->rp.last_multiplier;
+    return PDL_OK;
+}
+
+int pdl_get_timings(pdl_ctx *c, pdl_timings *out) {
+    if (!c || !out) return PDL_ERR_ARGUMENT;
+    std::lock_guard<std::mutex> lk(c->mu);
+    *out = c->tm;
+    return PDL_OK;
+}
+
+}  // extern "C"

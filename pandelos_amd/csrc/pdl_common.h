@@ -1,0 +1,175 @@
+// pdl_common.h — shared declarations of the HIP implementation behind include/pandelos_amd.h.
+// gfx950 only: wave = 64 lanes, 160 KiB LDS per CU, no other target is considered.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/pandelos_amd.h"
+
+#define PDL_WAVE 64
+
+// ---- error plumbing -------------------------------------------------------------------------
+struct pdl_error {
+    int code;
+    std::string msg;
+};
+
+#define PDL_HIP(expr)                                                                           \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            throw pdl_error{PDL_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)}; \
+        }                                                                                       \
+    } while (0)
+
+#define PDL_FAIL(code_, ...)                                  \
+    do {                                                      \
+        char _b[512];                                         \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);                \
+        throw pdl_error{(code_), std::string(_b)};            \
+    } while (0)
+
+// ---- device buffer ----------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    void alloc(size_t n) {            // grows only; contents undefined
+        if (n <= bytes && p) return;
+        release();
+        size_t want = n ? n : 16;
+        PDL_HIP(hipMalloc(&p, want));
+        bytes = want;
+    }
+    void release() {
+        if (p) (void) hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+    ~DevBuf() { release(); }
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+};
+
+// ---- alphabet / rank parameters (library.cpp:56-64, 88-132) -----------------------------------
+struct RankParams {
+    uint8_t rank_values[256];
+    uint64_t last_multiplier;
+    uint32_t base;          // B (kept as the reference's unsigned char value)
+    uint32_t k;
+    uint32_t rank_bits;
+    uint32_t hash_fallback;
+};
+
+struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    bool used = false;
+};
+
+// ---- the context --------------------------------------------------------------------------------
+struct pdl_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    uint32_t flags = 0;
+    std::string err;
+    std::mutex mu;
+
+    // inputs (device)
+    const uint8_t *d_res = nullptr;
+    const uint64_t *d_off = nullptr;
+    const uint32_t *d_gen = nullptr;
+    DevBuf in_res, in_off, in_gen;
+
+    bool preprocessed = false;
+    bool only_complexity = false;
+    uint32_t N = 0, G = 0;
+    uint64_t R = 0, M = 0, U = 0, Ushared = 0, NG = 0, P = 0, sum_kseq = 0, max_kseq = 0;
+    RankParams rp{};
+
+    // per sequence
+    DevBuf kseq_len;      // u32 [N]
+    DevBuf kmer_off;      // u64 [N+1]
+    DevBuf cost;          // u64 [N]   total_visited
+    DevBuf genome_cost;   // u64 [G]
+    std::vector<uint64_t> h_genome_cost;
+
+    // sort buffers / dictionary
+    DevBuf keys_a, keys_b, vals_a, vals_b, sort_tmp;
+    bool key64 = false;
+    DevBuf recpos;        // u32 [U+1] position of each record's first occurrence in the sorted stream
+    DevBuf post;          // uint2 [U] {seq, count}  — the dictionary postings, rank-group major
+    DevBuf gid;           // u32 [U] group index of each record
+    DevBuf goff;          // u32 [NG+1] first record of each group
+    DevBuf ranges;        // uint4 [U'] {group start, group length, own count, 0}, gene major
+    DevBuf seq_off;       // u32 [N+1] range list of each gene
+    DevBuf scan_tmp;      // block sums of the scans
+    DevBuf scratch;       // transient buffers of the range build
+    DevBuf scalars;       // u64 [16] device-side totals
+    DevBuf hist;          // u64 [256]
+
+    // genome / task layout (host and device)
+    std::vector<uint32_t> h_genome_of;
+    std::vector<uint32_t> h_genome_row_off;   // [G+1] into h_genome_rows
+    std::vector<uint32_t> h_genome_rows;      // gene ids grouped by genome, ascending inside a genome
+    std::vector<uint32_t> shard;              // genomes scored by this context (ascending)
+    bool shard_set = false;
+
+    // scoring results (device)
+    bool scored = false;
+    uint32_t n_task_rows = 0;
+    std::vector<int32_t> h_local_genome;      // [G] genome -> index in shard or -1
+    std::vector<uint32_t> h_task_row_off;     // [shard+1] task position of each shard genome's first row
+    std::vector<uint64_t> h_cell_off;         // [shard+1] first cell of each shard genome
+    DevBuf task_rows;     // u32 [n_task_rows] gene id of each task position
+    DevBuf task_lg;       // u32 [n_task_rows] shard-local genome index
+    DevBuf MS;            // f32 [n_task_rows][G]      max_genome_score rows
+    DevBuf CM;            // f32 [shard][N]            max_genome_score_col per genome task
+    DevBuf row_base, row_cnt, fin_off;   // u32 [n_task_rows(+1)]
+    DevBuf st_score, st_perc, st_tr, st_col, st_first;   // staging cells (unordered inside a row)
+    uint64_t st_cap = 0;
+    DevBuf c_score, c_perc, c_tr, c_row, c_col;          // final cells, task order + emission order
+    uint64_t Z = 0;
+    DevBuf join_ctr;      // u32 [8] cursors/counters of the join
+    DevBuf overflow_rows; // u32 [n_task_rows]
+    DevBuf glb_table;     // HBM tables of the overflow pass
+
+    pdl_timings tm{};
+    EventPair ev[12];
+};
+
+// stage entry points (pdl_dict.hip / pdl_join.hip)
+void pdl_run_preprocess(pdl_ctx *c, int kvalue, bool only_complexity);
+void pdl_run_score_all(pdl_ctx *c);
+
+// event helpers
+enum { EV_HIST, EV_RANK, EV_SORT1, EV_DICT, EV_SORT2, EV_RANGES, EV_JOIN, EV_JOIN_OVF, EV_ORDER, EV_PRE_TOTAL, EV_SCORE_TOTAL, EV_COUNT };
+
+inline void ev_begin(pdl_ctx *c, int i) {
+    if (!c->ev[i].a) { PDL_HIP(hipEventCreate(&c->ev[i].a)); PDL_HIP(hipEventCreate(&c->ev[i].b)); }
+    PDL_HIP(hipEventRecord(c->ev[i].a, c->stream));
+    c->ev[i].used = false;
+}
+inline void ev_end(pdl_ctx *c, int i) {
+    PDL_HIP(hipEventRecord(c->ev[i].b, c->stream));
+    c->ev[i].used = true;
+}
+inline float ev_ms(pdl_ctx *c, int i) {
+    if (!c->ev[i].used) return 0.f;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->ev[i].a, c->ev[i].b) != hipSuccess) return 0.f;
+    return ms;
+}
+
+static inline uint32_t bit_length64(uint64_t v) {
+    uint32_t b = 0;
+    while (v) { b++; v >>= 1; }
+    return b;
+}

@@ -1,0 +1,482 @@
+// pdl_dict.hip — the dictionary stage on the device: everything preprocessSequences does
+// (ig/native/library.cpp:189-371), one kernel (or kernel group) per reference function:
+//
+//   K-hist    k_hist              alphabet histogram                         library.cpp:216-228
+//   (host)    rank_init_host      rank table, B^(k-1), overflow -> hashing   library.cpp:88-132
+//   K-len     k_kseq_len          kseq_lengths + k-mer stream offsets        library.cpp:250-262
+//   K-rank    k_rank / k_rank_hash   per-gene k-mer ranks                    library.cpp:75-86,134-150
+//   K-sort    pdl_sort_pairs      stable LSD radix sort by rank              library.cpp:172-187,270-278
+//   K-rle     RecHead/RecScatter, k_build_records   dedup -> (rank,gene,count)   library.cpp:280-287
+//   K-groups  GroupHead scan, k_group_offsets, k_record_costs (+ the last-record fold)  library.cpp:297-335
+//   K-ranges  SharedFlag compaction, sort by gene, k_build_ranges, k_seq_offsets   library.cpp:318-326
+//   K-cost    k_genome_cost       per-genome and total lookups               library.cpp:337-350,535-538
+//
+// HBM layout after this stage (what the join reads):
+//   post   uint2[U]   {gene, count}       rank-group major, ascending gene inside a group
+//   ranges uint4[U']  {group start, group length, own count, 0}   gene major (U' = records in groups >= 2)
+//   seq_off u32[N+1]  range list of each gene;   kseq_len u32[N];   cost u64[N]
+#include "pdl_common.h"
+#include "pdl_scan.h"
+#include "pdl_sort.h"
+
+#include <algorithm>
+#include <cstring>
+
+#define RABIN_MODULO 18446744073709551557ULL   /* 2^64 - 59, library.cpp:19 */
+
+// ------------------------------------------------------------------------------------------------
+// K-hist: 256-bin histogram of the residue bytes (library.cpp:216-228).  16-byte coalesced loads,
+// per-workgroup LDS histogram (4 interleaved copies to thin out same-address atomics on
+// low-entropy input), one global atomic per non-empty bin per workgroup.
+// ------------------------------------------------------------------------------------------------
+constexpr int HIST_THREADS = 256;
+__global__ __launch_bounds__(HIST_THREADS) void k_hist(const uint8_t *__restrict__ res, uint64_t n, unsigned long long *__restrict__ hist) {
+    __shared__ uint32_t s_h[4][256];
+    for (int i = threadIdx.x; i < 4 * 256; i += HIST_THREADS) (&s_h[0][0])[i] = 0;
+    __syncthreads();
+    const int copy = threadIdx.x & 3;
+    const uint64_t n16 = n / 16;
+    const uint4 *res16 = reinterpret_cast<const uint4 *>(res);
+    const uint64_t stride = (uint64_t) gridDim.x * HIST_THREADS;
+    for (uint64_t i = (uint64_t) blockIdx.x * HIST_THREADS + threadIdx.x; i < n16; i += stride) {
+        uint4 v = res16[i];
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            atomicAdd(&s_h[copy][w[j] & 0xff], 1u);
+            atomicAdd(&s_h[copy][(w[j] >> 8) & 0xff], 1u);
+            atomicAdd(&s_h[copy][(w[j] >> 16) & 0xff], 1u);
+            atomicAdd(&s_h[copy][w[j] >> 24], 1u);
+        }
+    }
+    if (blockIdx.x == 0) {   // tail bytes
+        for (uint64_t i = n16 * 16 + threadIdx.x; i < n; i += HIST_THREADS) atomicAdd(&s_h[0][res[i]], 1u);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < 256; b += HIST_THREADS) {
+        uint32_t t = s_h[0][b] + s_h[1][b] + s_h[2][b] + s_h[3][b];
+        if (t) atomicAdd(&hist[b], (unsigned long long) t);
+    }
+}
+
+// library.cpp:88-132, literally (64-bit wraparound included); adds rank_bits for the device sort.
+static void rank_init_host(RankParams &rp, const uint64_t counters[256], int kvalue) {
+    memset(&rp, 0, sizeof(rp));
+    rp.k = (uint32_t) kvalue;
+    int rank = 0;
+    for (int i = 0; i < 256; i++)
+        if (counters[i] > 0) rp.rank_values[i] = (uint8_t) rank++;
+    const uint8_t rank_base = (uint8_t) rank;
+    rp.base = rank_base;
+    uint64_t last_multiplier = 1;
+    bool has_overflow = false;
+    int tmp_kvalue = kvalue - 1;
+    while (tmp_kvalue--) {
+        uint64_t ovflw_test = last_multiplier;
+        last_multiplier *= rank_base;
+        if (has_overflow) {
+            last_multiplier %= RABIN_MODULO;
+        } else if ((ovflw_test > last_multiplier) || (ovflw_test * rank_base > last_multiplier * rank_base)) {
+            has_overflow = true;
+            last_multiplier = ((ovflw_test % RABIN_MODULO) * rank_base) % RABIN_MODULO;
+        }
+    }
+    rp.last_multiplier = last_multiplier;
+    rp.hash_fallback = has_overflow ? 1u : 0u;
+    if (has_overflow) {
+        rp.rank_bits = 64;
+    } else {
+        uint64_t rank_tmp = last_multiplier * rank_base;   // B^k, fits (the loop above looked one step ahead)
+        rp.rank_bits = rank_tmp ? bit_length64(rank_tmp - 1) : 1;
+        if (rp.rank_bits == 0) rp.rank_bits = 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K-len: kseq_lengths (library.cpp:250-262).  The exclusive scan of these is the offset of each
+// gene in the k-mer stream (gene order = the order the reference emplace_back()s them, :255-258).
+// ------------------------------------------------------------------------------------------------
+struct KseqFlag {
+    const uint64_t *off; uint32_t k;
+    __device__ uint32_t operator()(uint64_t i) const {
+        uint64_t len = off[i + 1] - off[i];
+        return len >= k ? (uint32_t) (len - k + 1) : 0u;
+    }
+};
+struct KseqApply {
+    uint32_t *kseq_len; uint64_t *kmer_off;   // kmer_off as u64 for the API; values < 2^32 (checked on the host)
+    __device__ void operator()(uint64_t i, uint32_t f, uint32_t prefix) const {
+        kseq_len[i] = f;
+        kmer_off[i] = prefix;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// K-rank (exact): one thread per k-mer of the stream.  Because B^k < 2^64 here, the reference's
+// rolling update (library.cpp:75-79) equals the direct base-B polynomial of the k residues, so
+// k-mers are independent.  A workgroup covers RANK_TILE consecutive stream slots; two lanes
+// bracket the genes of the tile with a binary search, every lane then searches only that bracket.
+// ------------------------------------------------------------------------------------------------
+constexpr int RANK_THREADS = 256;
+constexpr int RANK_ITEMS = 4;
+constexpr int RANK_TILE = RANK_THREADS * RANK_ITEMS;
+
+__device__ __forceinline__ uint32_t upper_bound_u64(const uint64_t *a, uint32_t lo, uint32_t hi, uint64_t v) {
+    // first index in [lo,hi) with a[idx] > v
+    while (lo < hi) {
+        uint32_t mid = lo + ((hi - lo) >> 1);
+        if (a[mid] <= v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+template <class KeyT>
+__global__ __launch_bounds__(RANK_THREADS) void k_rank(const uint8_t *__restrict__ res, const uint64_t *__restrict__ off,
+                                                       const uint64_t *__restrict__ kmer_off, uint32_t n_seq, uint64_t m,
+                                                       RankParams rp, KeyT *__restrict__ keys, uint32_t *__restrict__ vals) {
+    __shared__ uint8_t s_rv[256];
+    __shared__ uint32_t s_lo, s_hi;
+    for (int i = threadIdx.x; i < 256; i += RANK_THREADS) s_rv[i] = rp.rank_values[i];
+    const uint64_t q0 = (uint64_t) blockIdx.x * RANK_TILE;
+    const uint64_t q_last = min(q0 + RANK_TILE, m) - 1;
+    if (threadIdx.x == 0) s_lo = upper_bound_u64(kmer_off, 0, n_seq + 1, q0) - 1;
+    if (threadIdx.x == 64) s_hi = upper_bound_u64(kmer_off, 0, n_seq + 1, q_last) - 1;
+    __syncthreads();
+    const uint32_t lo = s_lo, hi = s_hi;
+    const uint32_t k = rp.k;
+    const uint64_t base = rp.base;
+#pragma unroll
+    for (int j = 0; j < RANK_ITEMS; j++) {
+        const uint64_t q = q0 + (uint64_t) j * RANK_THREADS + threadIdx.x;
+        if (q >= m) break;
+        const uint32_t s = upper_bound_u64(kmer_off, lo, hi + 1, q) - 1;   // kmer_off[s] <= q < kmer_off[s+1]
+        const uint8_t *p = res + off[s] + (q - kmer_off[s]);
+        uint64_t r = 0;
+        for (uint32_t i = 0; i < k; i++) r = r * base + s_rv[p[i]];
+        keys[q] = (KeyT) r;
+        vals[q] = s;
+    }
+}
+
+// K-rank (hash fallback, library.cpp:81-86): the 64-bit wrap of the first line makes the value
+// depend on the whole prefix of the gene, so genes are ranked sequentially, one lane per gene.
+__device__ __forceinline__ uint64_t update_rank_hash_dev(uint64_t current, uint64_t vnext, uint64_t vpop, uint64_t lm, uint64_t base) {
+    uint64_t wrapped = current + RABIN_MODULO - vpop * lm;       // evaluated in 64 bits, wraps
+    // (wrapped * base + vnext) mod (2^64 - 59) with a 128-bit intermediate
+    uint64_t lo = wrapped * base;
+    uint64_t hi = __umul64hi(wrapped, base);
+    uint64_t lo2 = lo + vnext;
+    hi += (lo2 < lo);
+    // hi * 2^64 + lo2  ==  hi * 59 + lo2   (mod 2^64 - 59); hi < 256 so hi*59 is tiny
+    uint64_t t = hi * 59ull;
+    uint64_t r = lo2 + t;
+    if (r < lo2) r += 59ull;                                     // one more 2^64 folded (cannot carry again)
+    if (r >= RABIN_MODULO) r -= RABIN_MODULO;
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_rank_hash(const uint8_t *__restrict__ res, const uint64_t *__restrict__ off,
+                                                   const uint64_t *__restrict__ kmer_off, uint32_t n_seq, RankParams rp,
+                                                   uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+    __shared__ uint8_t s_rv[256];
+    for (int i = threadIdx.x; i < 256; i += 256) s_rv[i] = rp.rank_values[i];
+    __syncthreads();
+    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_seq) return;
+    const uint64_t b = off[s], e = off[s + 1];
+    const uint32_t k = rp.k;
+    if (e - b < k) return;
+    const uint8_t *p = res + b;
+    const uint64_t len = e - b;
+    uint64_t q = kmer_off[s];
+    uint64_t rank = 0;
+    const uint64_t v0 = s_rv[0];
+    for (uint32_t i = 0; i < k; i++) rank = update_rank_hash_dev(rank, s_rv[p[i]], v0, rp.last_multiplier, rp.base);
+    keys[q] = rank; vals[q] = s; q++;
+    for (uint64_t i = k; i < len; i++) {
+        rank = update_rank_hash_dev(rank, s_rv[p[i]], s_rv[p[i - k]], rp.last_multiplier, rp.base);
+        keys[q] = rank; vals[q] = s; q++;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K-rle: run-length dedup of the sorted stream (library.cpp:280-287).  A record head is a position
+// whose (rank, gene) differs from its predecessor; recpos[u] = position of the u-th head, the run
+// length to the next head is the k-mer's multiplicity in the gene.
+// ------------------------------------------------------------------------------------------------
+template <class KeyT> struct RecHead {
+    const KeyT *keys; const uint32_t *vals;
+    __device__ uint32_t operator()(uint64_t q) const {
+        return (q == 0 || keys[q] != keys[q - 1] || vals[q] != vals[q - 1]) ? 1u : 0u;
+    }
+};
+struct RecScatter {
+    uint32_t *recpos;
+    __device__ void operator()(uint64_t q, uint32_t f, uint32_t prefix) const { if (f) recpos[prefix] = (uint32_t) q; }
+};
+
+// post[u] = {gene, count}; ghead[u] = 1 when record u opens a rank-group.  The reference's scan
+// (library.cpp:300-306) closes the current group at the LAST record with end = i + 1 whatever its
+// rank, i.e. the last record never opens a group: when it is the only record of the largest rank
+// it is folded into the preceding group.  (The reference then re-sorts that group by gene, :312-315;
+// nothing downstream of this dictionary depends on the order inside a group, so no re-sort here.)
+template <class KeyT>
+__global__ __launch_bounds__(256) void k_build_records(const KeyT *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                                       const uint32_t *__restrict__ recpos, uint64_t m, uint32_t u_count,
+                                                       uint2 *__restrict__ post, uint8_t *__restrict__ ghead) {
+    const uint32_t u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= u_count) return;
+    const uint32_t q = recpos[u];
+    const uint32_t qn = (u + 1 < u_count) ? recpos[u + 1] : (uint32_t) m;
+    post[u] = make_uint2(vals[q], qn - q);
+    uint8_t h = 1;
+    if (u > 0) h = keys[q] != keys[recpos[u - 1]];
+    if (u_count >= 2 && u == u_count - 1) h = 0;
+    ghead[u] = h;
+}
+
+struct GroupHeadFlag {
+    const uint8_t *ghead;
+    __device__ uint32_t operator()(uint64_t u) const { return ghead[u]; }
+};
+struct GroupScatter {
+    uint32_t *gid; uint32_t *goff;
+    __device__ void operator()(uint64_t u, uint32_t f, uint32_t prefix) const {
+        gid[u] = prefix + f - 1;           // inclusive count - 1
+        if (f) goff[prefix] = (uint32_t) u;
+    }
+};
+__global__ void k_close_offsets(uint32_t *goff, const uint64_t *d_ng, uint32_t u_count) { goff[*d_ng] = u_count; }
+
+// total_visited (library.cpp:327): every record of a group with >= 2 records adds the group size
+// to its gene.  Also the flag of the compaction that follows.
+__global__ __launch_bounds__(256) void k_record_costs(const uint2 *__restrict__ post, const uint32_t *__restrict__ gid,
+                                                      const uint32_t *__restrict__ goff, uint32_t u_count,
+                                                      unsigned long long *__restrict__ cost) {
+    const uint32_t u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= u_count) return;
+    const uint32_t g = gid[u];
+    const uint32_t len = goff[g + 1] - goff[g];
+    if (len >= 2) atomicAdd(&cost[post[u].x], (unsigned long long) len);
+}
+
+struct SharedFlag {
+    const uint32_t *gid; const uint32_t *goff;
+    __device__ uint32_t operator()(uint64_t u) const { uint32_t g = gid[u]; return (goff[g + 1] - goff[g]) >= 2 ? 1u : 0u; }
+};
+struct SharedScatter {
+    const uint2 *post; uint32_t *key2; uint32_t *val2;
+    __device__ void operator()(uint64_t u, uint32_t f, uint32_t prefix) const {
+        if (f) { key2[prefix] = post[u].x; val2[prefix] = (uint32_t) u; }
+    }
+};
+struct SharedGroupFlag {   // groups with >= 2 records, for the statistics only
+    const uint32_t *goff;
+    __device__ uint32_t operator()(uint64_t g) const { return (goff[g + 1] - goff[g]) >= 2 ? 1u : 0u; }
+};
+struct NoApply { __device__ void operator()(uint64_t, uint32_t, uint32_t) const {} };
+
+// K-ranges: the per-gene posting-range lists (kmers_ranges, library.cpp:318-326) as flat uint4.
+__global__ __launch_bounds__(256) void k_build_ranges(const uint32_t *__restrict__ rec_sorted, const uint2 *__restrict__ post,
+                                                      const uint32_t *__restrict__ gid, const uint32_t *__restrict__ goff,
+                                                      uint32_t n, uint4 *__restrict__ ranges) {
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const uint32_t u = rec_sorted[e];
+    const uint32_t g = gid[u];
+    const uint32_t gs = goff[g];
+    ranges[e] = make_uint4(gs, goff[g + 1] - gs, post[u].y, 0u);
+}
+
+// seq_off[s] = first range of gene s in the gene-sorted list (lower bound), seq_off[N] = U'
+__global__ __launch_bounds__(256) void k_seq_offsets(const uint32_t *__restrict__ seq_sorted, uint32_t n, uint32_t n_seq,
+                                                     uint32_t *__restrict__ seq_off) {
+    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+    if (s > n_seq) return;
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        uint32_t mid = lo + ((hi - lo) >> 1);
+        if (seq_sorted[mid] < s) lo = mid + 1; else hi = mid;
+    }
+    seq_off[s] = lo;
+}
+
+// K-cost: per-genome cost (library.cpp:535-538); the total is their sum (library.cpp:337-349).
+__global__ __launch_bounds__(256) void k_genome_cost(const unsigned long long *__restrict__ cost, const uint32_t *__restrict__ kseq_len,
+                                                     const uint32_t *__restrict__ genome_of, uint32_t n_seq,
+                                                     unsigned long long *__restrict__ genome_cost, unsigned long long *__restrict__ sum_kseq,
+                                                     unsigned long long *__restrict__ max_kseq) {
+    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_seq) return;
+    unsigned long long c = cost[s];
+    if (c) atomicAdd(&genome_cost[genome_of[s]], c);
+    uint32_t kl = kseq_len[s];
+    if (kl) { atomicAdd(sum_kseq, (unsigned long long) kl); atomicMax(max_kseq, (unsigned long long) kl); }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <class KeyT>
+static void dictionary_pipeline(pdl_ctx *c, bool only_complexity) {
+    hipStream_t st = c->stream;
+    const uint64_t M = c->M;
+    uint64_t *d_scal = c->scalars.as<uint64_t>();
+
+    // K-rank
+    ev_begin(c, EV_RANK);
+    c->keys_a.alloc(M * sizeof(KeyT)); c->keys_b.alloc(M * sizeof(KeyT));
+    c->vals_a.alloc(M * sizeof(uint32_t)); c->vals_b.alloc(M * sizeof(uint32_t));
+    KeyT *keys_in = c->keys_a.as<KeyT>(), *keys_out = c->keys_b.as<KeyT>();
+    uint32_t *vals_in = c->vals_a.as<uint32_t>(), *vals_out = c->vals_b.as<uint32_t>();
+    if (c->rp.hash_fallback) {
+        if constexpr (sizeof(KeyT) == 8) {
+            hipLaunchKernelGGL(k_rank_hash, dim3((c->N + 255) / 256), dim3(256), 0, st, c->d_res, c->d_off,
+                               c->kmer_off.as<uint64_t>(), c->N, c->rp, keys_in, vals_in);
+        }
+    } else {
+        const uint64_t tiles = (M + RANK_TILE - 1) / RANK_TILE;
+        hipLaunchKernelGGL((k_rank<KeyT>), dim3((uint32_t) tiles), dim3(RANK_THREADS), 0, st, c->d_res, c->d_off,
+                           c->kmer_off.as<uint64_t>(), c->N, M, c->rp, keys_in, vals_in);
+    }
+    PDL_HIP(hipGetLastError());
+    ev_end(c, EV_RANK);
+
+    // K-sort: stable by rank; gene order of equal ranks is the stream order = ascending gene
+    ev_begin(c, EV_SORT1);
+    pdl_sort_pairs<KeyT>(c, keys_in, keys_out, vals_in, vals_out, M, c->rp.rank_bits);
+    ev_end(c, EV_SORT1);
+    // remember which physical buffers hold the sorted stream (pdl_get_dictionary reads them)
+    if ((void *) keys_out != c->keys_b.p) { std::swap(c->keys_a.p, c->keys_b.p); std::swap(c->keys_a.bytes, c->keys_b.bytes); }
+    if ((void *) vals_out != c->vals_b.p) { std::swap(c->vals_a.p, c->vals_b.p); std::swap(c->vals_a.bytes, c->vals_b.bytes); }
+    const KeyT *skeys = c->keys_b.as<KeyT>();
+    const uint32_t *svals = c->vals_b.as<uint32_t>();
+
+    // K-rle
+    ev_begin(c, EV_DICT);
+    c->recpos.alloc((M + 1) * sizeof(uint32_t));
+    scan_and_apply(c, M, RecHead<KeyT>{skeys, svals}, RecScatter{c->recpos.as<uint32_t>()}, d_scal + 0);
+    uint64_t U = 0;
+    PDL_HIP(hipMemcpyAsync(&U, d_scal + 0, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    PDL_HIP(hipStreamSynchronize(st));
+    c->U = U;
+    const uint32_t Uu = (uint32_t) U;
+    const uint32_t ublocks = (Uu + 255) / 256;
+
+    c->post.alloc(U * sizeof(uint2));
+    c->gid.alloc(U * sizeof(uint32_t));
+    c->goff.alloc((U + 2) * sizeof(uint32_t));
+    uint8_t *ghead = reinterpret_cast<uint8_t *>(c->keys_a.p);   // keys_a is free after the sort (>= M bytes)
+    hipLaunchKernelGGL((k_build_records<KeyT>), dim3(ublocks), dim3(256), 0, st, skeys, svals, c->recpos.as<uint32_t>(), M, Uu,
+                       c->post.as<uint2>(), ghead);
+    // K-groups
+    scan_and_apply(c, U, GroupHeadFlag{ghead}, GroupScatter{c->gid.as<uint32_t>(), c->goff.as<uint32_t>()}, d_scal + 1);
+    hipLaunchKernelGGL(k_close_offsets, dim3(1), dim3(1), 0, st, c->goff.as<uint32_t>(), d_scal + 1, Uu);
+    c->cost.alloc((size_t) c->N * sizeof(uint64_t));
+    PDL_HIP(hipMemsetAsync(c->cost.p, 0, (size_t) c->N * sizeof(uint64_t), st));
+    hipLaunchKernelGGL(k_record_costs, dim3(ublocks), dim3(256), 0, st, c->post.as<uint2>(), c->gid.as<uint32_t>(),
+                       c->goff.as<uint32_t>(), Uu, c->cost.as<unsigned long long>());
+    PDL_HIP(hipGetLastError());
+    ev_end(c, EV_DICT);
+
+    // K-cost
+    c->genome_cost.alloc((size_t) c->G * sizeof(uint64_t));
+    PDL_HIP(hipMemsetAsync(c->genome_cost.p, 0, (size_t) c->G * sizeof(uint64_t), st));
+    PDL_HIP(hipMemsetAsync(d_scal + 4, 0, sizeof(uint64_t), st));
+    PDL_HIP(hipMemsetAsync(d_scal + 7, 0, sizeof(uint64_t), st));
+    hipLaunchKernelGGL(k_genome_cost, dim3((c->N + 255) / 256), dim3(256), 0, st, c->cost.as<unsigned long long>(),
+                       c->kseq_len.as<uint32_t>(), c->d_gen, c->N, c->genome_cost.as<unsigned long long>(),
+                       reinterpret_cast<unsigned long long *>(d_scal + 4), reinterpret_cast<unsigned long long *>(d_scal + 7));
+
+    if (!only_complexity) {
+        // K-ranges: compact the records of shared groups, sort them by gene, expand to uint4 ranges
+        ev_begin(c, EV_SORT2);
+        // scratch: key2 goes to vals_a (M u32, free after the sort; keys_a's first U bytes hold ghead)
+        c->scratch.alloc(3 * U * sizeof(uint32_t));
+        uint32_t *k2a = c->vals_a.as<uint32_t>();
+        uint32_t *v2a = c->scratch.as<uint32_t>();
+        uint32_t *k2b = c->scratch.as<uint32_t>() + U;
+        uint32_t *v2b = c->scratch.as<uint32_t>() + 2 * U;
+        scan_and_apply(c, U, SharedFlag{c->gid.as<uint32_t>(), c->goff.as<uint32_t>()},
+                       SharedScatter{c->post.as<uint2>(), k2a, v2a}, d_scal + 2);
+        uint64_t Us = 0;
+        PDL_HIP(hipMemcpyAsync(&Us, d_scal + 2, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        PDL_HIP(hipStreamSynchronize(st));
+        c->Ushared = Us;
+        const uint32_t seq_bits = std::max<uint32_t>(1, bit_length64(c->N ? c->N - 1 : 0));
+        pdl_sort_pairs<uint32_t>(c, k2a, k2b, v2a, v2b, Us, seq_bits);     // sorted pairs now in (k2b, v2b)
+        ev_end(c, EV_SORT2);
+
+        ev_begin(c, EV_RANGES);
+        c->ranges.alloc(Us * sizeof(uint4));
+        c->seq_off.alloc(((size_t) c->N + 1) * sizeof(uint32_t));
+        if (Us) hipLaunchKernelGGL(k_build_ranges, dim3(((uint32_t) Us + 255) / 256), dim3(256), 0, st, v2b, c->post.as<uint2>(),
+                                   c->gid.as<uint32_t>(), c->goff.as<uint32_t>(), (uint32_t) Us, c->ranges.as<uint4>());
+        hipLaunchKernelGGL(k_seq_offsets, dim3((c->N + 1 + 255) / 256), dim3(256), 0, st, k2b, (uint32_t) Us, c->N, c->seq_off.as<uint32_t>());
+        PDL_HIP(hipGetLastError());
+        ev_end(c, EV_RANGES);
+    }
+
+    // statistics: number of shared groups
+    uint64_t NGall = 0;
+    PDL_HIP(hipMemcpyAsync(&NGall, d_scal + 1, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    PDL_HIP(hipStreamSynchronize(st));
+    scan_and_apply(c, NGall, SharedGroupFlag{c->goff.as<uint32_t>()}, NoApply{}, d_scal + 3);
+    c->h_genome_cost.assign(c->G, 0);
+    PDL_HIP(hipMemcpyAsync(c->h_genome_cost.data(), c->genome_cost.p, (size_t) c->G * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    uint64_t tail[2] = {0, 0};
+    PDL_HIP(hipMemcpyAsync(tail, d_scal + 3, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    PDL_HIP(hipStreamSynchronize(st));
+    c->NG = tail[0];
+    c->sum_kseq = tail[1];
+    PDL_HIP(hipMemcpyAsync(&c->max_kseq, d_scal + 7, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    PDL_HIP(hipStreamSynchronize(st));
+    c->P = 0;
+    for (uint64_t v : c->h_genome_cost) c->P += v;
+}
+
+void pdl_run_preprocess(pdl_ctx *c, int kvalue, bool only_complexity) {
+    hipStream_t st = c->stream;
+    if (kvalue <= 0) PDL_FAIL(PDL_ERR_KVALUE, "K value must be greater than 0.");
+    ev_begin(c, EV_PRE_TOTAL);
+    c->scalars.alloc(16 * sizeof(uint64_t));
+    c->hist.alloc(256 * sizeof(uint64_t));
+
+    // K-hist
+    ev_begin(c, EV_HIST);
+    PDL_HIP(hipMemsetAsync(c->hist.p, 0, 256 * sizeof(uint64_t), st));
+    if (c->R) {
+        uint32_t blocks = (uint32_t) std::min<uint64_t>((c->R / 16 + HIST_THREADS - 1) / HIST_THREADS + 1, 2048);
+        hipLaunchKernelGGL(k_hist, dim3(blocks), dim3(HIST_THREADS), 0, st, c->d_res, c->R, c->hist.as<unsigned long long>());
+    }
+    // K-len (independent of the histogram)
+    c->kseq_len.alloc((size_t) c->N * sizeof(uint32_t));
+    c->kmer_off.alloc(((size_t) c->N + 1) * sizeof(uint64_t));
+    uint64_t *d_scal = c->scalars.as<uint64_t>();
+    scan_and_apply(c, c->N, KseqFlag{c->d_off, (uint32_t) kvalue}, KseqApply{c->kseq_len.as<uint32_t>(), c->kmer_off.as<uint64_t>()}, d_scal + 5);
+    PDL_HIP(hipMemcpyAsync(c->kmer_off.as<uint64_t>() + c->N, d_scal + 5, sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+    uint64_t counters[256];
+    uint64_t M = 0;
+    PDL_HIP(hipMemcpyAsync(counters, c->hist.p, sizeof(counters), hipMemcpyDeviceToHost, st));
+    PDL_HIP(hipMemcpyAsync(&M, d_scal + 5, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    ev_end(c, EV_HIST);
+    PDL_HIP(hipStreamSynchronize(st));
+
+    rank_init_host(c->rp, counters, kvalue);
+    c->M = M;
+    c->only_complexity = only_complexity;
+    if (M == 0) PDL_FAIL(PDL_ERR_EMPTY, "no gene is at least k=%d residues long: the dictionary is empty", kvalue);
+    // the scan above sums in 32 bits: make sure it cannot have wrapped, and keep stream positions in u32
+    if (c->R >= 0xfffffff0ull) PDL_FAIL(PDL_ERR_UNSUPPORTED, "more than 2^32 residues (%llu) need 64-bit stream positions", (unsigned long long) c->R);
+
+    c->key64 = c->rp.rank_bits > 32;
+    if (c->key64) dictionary_pipeline<uint64_t>(c, only_complexity);
+    else dictionary_pipeline<uint32_t>(c, only_complexity);
+    ev_end(c, EV_PRE_TOTAL);
+    PDL_HIP(hipStreamSynchronize(st));
+    c->tm.hist_ms = ev_ms(c, EV_HIST);
+    c->tm.rank_ms = ev_ms(c, EV_RANK);
+    c->tm.sort_rank_ms = ev_ms(c, EV_SORT1);
+    c->tm.dict_ms = ev_ms(c, EV_DICT);
+    c->tm.sort_seq_ms = only_complexity ? 0.f : ev_ms(c, EV_SORT2);
+    c->tm.ranges_ms = only_complexity ? 0.f : ev_ms(c, EV_RANGES);
+    c->tm.preprocess_total_ms = ev_ms(c, EV_PRE_TOTAL);
+}

@@ -1,0 +1,130 @@
+// pdl_scan.h — device-wide "flag → exclusive prefix → apply" in three launches.
+//
+// Used for every compaction of the dictionary build (record heads, group heads, shared records,
+// per-row cell offsets).  The flag is recomputed from its inputs in both passes instead of being
+// materialised, so the only extra HBM traffic is one u32 per 2048-element tile.
+//
+//   pass 1  k_scan_tile_sums   tile sums of flag(i)                 -> tile_sums[t]
+//   pass 2  k_scan_tile_scan   exclusive scan of the tile sums (one workgroup), total -> *d_total
+//   pass 3  k_scan_apply       per tile: flags staged in LDS, workgroup exclusive scan,
+//                              apply(i, flag, exclusive_prefix)
+//
+// FlagF :  __device__ uint32_t operator()(uint64_t i) const      (any small count, not only 0/1)
+// ApplyF:  __device__ void operator()(uint64_t i, uint32_t flag, uint32_t exclusive_prefix) const
+#pragma once
+
+#include "pdl_common.h"
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;   // 2048
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v) {
+    const int lane = threadIdx.x & (PDL_WAVE - 1);
+#pragma unroll
+    for (int d = 1; d < PDL_WAVE; d <<= 1) {
+        uint32_t o = __shfl_up(v, d, PDL_WAVE);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// exclusive prefix of `v` over the workgroup (blockDim.x multiple of 64, <= 1024); returns the
+// exclusive prefix for this thread and the workgroup total through `total`.
+__device__ __forceinline__ uint32_t block_exclusive_scan_u32(uint32_t v, uint32_t *s_wave /* [17] */, uint32_t &total) {
+    const int lane = threadIdx.x & (PDL_WAVE - 1);
+    const int wave = threadIdx.x / PDL_WAVE;
+    const int nw = blockDim.x / PDL_WAVE;
+    uint32_t inc = wave_inclusive_scan_u32(v);
+    if (lane == PDL_WAVE - 1) s_wave[wave] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int w = 0; w < nw; w++) { uint32_t t = s_wave[w]; s_wave[w] = run; run += t; }
+        s_wave[16] = run;
+    }
+    __syncthreads();
+    uint32_t res = inc - v + s_wave[wave];
+    total = s_wave[16];
+    __syncthreads();
+    return res;
+}
+
+template <class FlagF>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_tile_sums(FlagF flag, uint64_t n, uint32_t *tile_sums) {
+    __shared__ uint32_t s_wave[17];
+    const uint64_t base = (uint64_t) blockIdx.x * SCAN_TILE;
+    uint32_t sum = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++) {
+        uint64_t i = base + (uint64_t) j * SCAN_THREADS + threadIdx.x;
+        if (i < n) sum += flag(i);
+    }
+    uint32_t total;
+    (void) block_exclusive_scan_u32(sum, s_wave, total);
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+
+// one workgroup of 1024 threads; tile_sums becomes its own exclusive scan
+static __global__ __launch_bounds__(1024) void k_scan_tile_scan(uint32_t *tile_sums, uint32_t n_tiles, uint64_t *d_total) {
+    __shared__ uint32_t s_wave[17];
+    __shared__ uint32_t s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_tiles; base += 1024) {
+        uint32_t i = base + threadIdx.x;
+        uint32_t v = i < n_tiles ? tile_sums[i] : 0;
+        uint32_t total;
+        uint32_t ex = block_exclusive_scan_u32(v, s_wave, total);
+        uint32_t carry = s_carry;
+        if (i < n_tiles) tile_sums[i] = ex + carry;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry = carry + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *d_total = s_carry;
+}
+
+template <class FlagF, class ApplyF>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(FlagF flag, ApplyF apply, uint64_t n, const uint32_t *tile_sums) {
+    __shared__ uint32_t s_flags[SCAN_TILE];
+    __shared__ uint32_t s_wave[17];
+    const uint64_t base = (uint64_t) blockIdx.x * SCAN_TILE;
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++) {           // coalesced flag evaluation
+        uint32_t li = j * SCAN_THREADS + threadIdx.x;
+        uint64_t i = base + li;
+        s_flags[li] = i < n ? flag(i) : 0u;
+    }
+    __syncthreads();
+    uint32_t f[SCAN_ITEMS];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++) { f[j] = s_flags[threadIdx.x * SCAN_ITEMS + j]; sum += f[j]; }
+    uint32_t total;
+    uint32_t prefix = block_exclusive_scan_u32(sum, s_wave, total) + tile_sums[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++) {
+        uint64_t i = base + (uint64_t) threadIdx.x * SCAN_ITEMS + j;
+        if (i < n) apply(i, f[j], prefix);
+        prefix += f[j];
+    }
+}
+
+// Host wrapper.  d_total receives the grand total (u64).  scan_tmp is grown as needed.
+template <class FlagF, class ApplyF>
+inline void scan_and_apply(pdl_ctx *c, uint64_t n, FlagF flag, ApplyF apply, uint64_t *d_total) {
+    if (n == 0) {
+        PDL_HIP(hipMemsetAsync(d_total, 0, sizeof(uint64_t), c->stream));
+        return;
+    }
+    const uint64_t tiles64 = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if (tiles64 > 0x7fffffffull) PDL_FAIL(PDL_ERR_UNSUPPORTED, "scan of %llu elements exceeds the grid limit", (unsigned long long) n);
+    const uint32_t tiles = (uint32_t) tiles64;
+    c->scan_tmp.alloc((size_t) tiles * sizeof(uint32_t));
+    uint32_t *ts = c->scan_tmp.as<uint32_t>();
+    hipLaunchKernelGGL((k_scan_tile_sums<FlagF>), dim3(tiles), dim3(SCAN_THREADS), 0, c->stream, flag, n, ts);
+    hipLaunchKernelGGL(k_scan_tile_scan, dim3(1), dim3(1024), 0, c->stream, ts, tiles, d_total);
+    hipLaunchKernelGGL((k_scan_apply<FlagF, ApplyF>), dim3(tiles), dim3(SCAN_THREADS), 0, c->stream, flag, apply, n, ts);
+    PDL_HIP(hipGetLastError());
+}

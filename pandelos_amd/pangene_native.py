@@ -1,0 +1,159 @@
+"""``PangeneNative`` — host-side mirror of ``ig/infoasys/cli/pangenes/PangeneNative.java`` over the C ABI.
+
+Same surface as the Java class: the constructor preprocesses (PangeneNative.java:5-7),
+``print_complexity`` is the ``-c`` mode (:10-12), ``generate_scores_part(genome, multithread)``
+returns one ``Scores`` block (:17-21).  Underneath are ``pdl_preprocess`` / ``pdl_compute_scores``
+of ``include/pandelos_amd.h``; errors come back as ``PdlError`` instead of the reference's
+``exit(1)`` (library.cpp:90-93).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .pangene_idata import PangeneIData
+from .scores import Scores
+
+
+def _np_copy(ptr, dtype, n):
+    if n == 0:
+        return np.zeros(0, dtype)
+    buf = (C.c_char * (np.dtype(dtype).itemsize * n)).from_address(C.cast(ptr, C.c_void_p).value)
+    return np.frombuffer(buf, dtype=dtype, count=n).copy()
+
+
+class PangeneNative:
+    def __init__(self, k: int, data: PangeneIData, only_complexity: bool = False, device: int = -1,
+                 stream: Optional[int] = None, flags: int = 0):
+        residues, offsets, genome_of = data.flatten()
+        self._init(k, residues, offsets, genome_of, only_complexity, device, stream, flags)
+
+    @classmethod
+    def from_arrays(cls, k, residues, offsets, genome_of, only_complexity=False, device=-1, stream=None, flags=0):
+        self = cls.__new__(cls)
+        self._init(k, residues, offsets, genome_of, only_complexity, device, stream, flags)
+        return self
+
+    @classmethod
+    def from_device(cls, k, d_residues: int, d_offsets: int, d_genome_of: int, n_sequences: int, n_residues: int,
+                    only_complexity=False, device=-1, stream=None, flags=0, keepalive=None):
+        """Device-resident inputs (raw device pointers, e.g. ``tensor.data_ptr()``)."""
+        self = cls.__new__(cls)
+        self._open(device, stream, flags)
+        self._keep = keepalive
+        self.cost = _lib.PdlCost()
+        rc = self._lib.pdl_preprocess_device(self._ctx, d_residues, d_offsets, d_genome_of, n_sequences, n_residues,
+                                             int(k), int(only_complexity), C.byref(self.cost))
+        self._check(rc)
+        return self
+
+    @staticmethod
+    def print_complexity(k: int, data: PangeneIData) -> "PangeneNative":
+        """PangeneNative.printComplexity (PangeneNative.java:10-12): cost model only."""
+        nat = PangeneNative(k, data, only_complexity=True)
+        c = nat.cost
+        print("------------\nCOMPUTATIONAL COSTS: ")
+        print(f"Total cost: {c.total_cost} lookups")
+        print(f"Linear ratio: {c.linear_ratio:g}\n------------\n")
+        return nat
+
+    # ------------------------------------------------------------------------------------------
+    def _open(self, device, stream, flags):
+        self._lib = _lib.load()
+        cfg = _lib.PdlConfig(device=device, stream=stream or None, flags=flags, reserved=0)
+        ctx = self._lib.pdl_create(C.byref(cfg))
+        if not ctx:
+            raise _lib.PdlError(_lib.PDL_ERR_DEVICE, self._lib.pdl_last_error(None).decode())
+        self._ctx = C.c_void_p(ctx)
+
+    def _init(self, k, residues, offsets, genome_of, only_complexity, device, stream, flags):
+        self._open(device, stream, flags)
+        res = np.ascontiguousarray(residues, dtype=np.uint8)
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        gen = np.ascontiguousarray(genome_of, dtype=np.uint32)
+        self.cost = _lib.PdlCost()
+        rc = self._lib.pdl_preprocess(self._ctx, res.ctypes.data, off.ctypes.data, gen.ctypes.data, len(gen), int(k),
+                                      int(only_complexity), C.byref(self.cost))
+        self._check(rc)
+
+    def _check(self, rc):
+        if rc != _lib.PDL_OK:
+            raise _lib.PdlError(rc, self._lib.pdl_last_error(self._ctx).decode())
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.pdl_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- reference surface ---------------------------------------------------------------------------
+    def generate_scores_part(self, genome: int, multithread: bool = False) -> Scores:
+        """PangeneNative.generateScoresPart (PangeneNative.java:17-21); ``multithread`` only selected the
+        ignored step_size in the reference (library.cpp:454)."""
+        s = _lib.PdlScores()
+        self._check(self._lib.pdl_compute_scores(self._ctx, int(genome), C.byref(s)))
+        try:
+            z, rows, g, n = s.scoresCount, s.rows, s.genomes, s.sequences
+            out = Scores(
+                scoresCount=z,
+                scores=_np_copy(s.scores, np.float32, z), percs=_np_copy(s.percs, np.float32, z),
+                tr_percs=_np_copy(s.tr_percs, np.float32, z),
+                row=_np_copy(s.row, np.int32, z), column=_np_copy(s.column, np.int32, z),
+                first_seq_genome=_np_copy(s.first_seq_genome, np.int32, z),
+                second_seq_genome=_np_copy(s.second_seq_genome, np.int32, z),
+                max_genome_score=_np_copy(s.max_genome_score, np.float32, rows * g).reshape(rows, g),
+                max_genome_score_col=_np_copy(s.max_genome_score_col, np.float32, n),
+                scoresMaxMappings=_np_copy(s.scoresMaxMappings, np.int32, n))
+        finally:
+            self._lib.pdl_free_scores(C.byref(s))
+        return out
+
+    # -- beyond the reference surface (device-resident batch, sharding, introspection) ------------------
+    def score_all(self) -> None:
+        self._check(self._lib.pdl_score_all(self._ctx))
+
+    def set_genome_shard(self, genomes: Sequence[int]) -> None:
+        g = np.ascontiguousarray(genomes, dtype=np.uint32)
+        self._check(self._lib.pdl_set_genome_shard(self._ctx, g.ctypes.data, len(g)))
+
+    def genome_cost(self, genome: int) -> int:
+        v = C.c_uint64()
+        self._check(self._lib.pdl_genome_cost(self._ctx, genome, C.byref(v)))
+        return v.value
+
+    def sequence_costs(self):
+        n = self.cost.sequences
+        cost = np.zeros(n, np.uint64)
+        kl = np.zeros(n, np.uint32)
+        self._check(self._lib.pdl_sequence_costs(self._ctx, cost.ctypes.data, kl.ctypes.data))
+        return cost, kl
+
+    def scores_counts(self) -> np.ndarray:
+        out = np.zeros(self.cost.genomes, np.uint32)
+        self._check(self._lib.pdl_scores_counts(self._ctx, out.ctypes.data))
+        return out
+
+    def dictionary(self):
+        u = self.cost.dictionary_records
+        ranks, seqs, counts = np.zeros(u, np.uint64), np.zeros(u, np.uint32), np.zeros(u, np.uint32)
+        self._check(self._lib.pdl_get_dictionary(self._ctx, ranks.ctypes.data, seqs.ctypes.data, counts.ctypes.data))
+        return ranks, seqs, counts
+
+    def rank_table(self):
+        tab = np.zeros(256, np.uint8)
+        lm = C.c_uint64()
+        self._check(self._lib.pdl_get_rank_table(self._ctx, tab.ctypes.data, C.byref(lm)))
+        return tab, lm.value
+
+    def timings(self) -> dict:
+        t = _lib.PdlTimings()
+        self._check(self._lib.pdl_get_timings(self._ctx, C.byref(t)))
+        return t.as_dict()

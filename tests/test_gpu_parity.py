@@ -1,0 +1,138 @@
+"""GPU parity: the HIP path through the C ABI (include/pandelos_amd.h) against
+  * the golden vectors the reference's own library.cpp produced (tests/golden/), and
+  * the CPU oracle (oracle/pangene_oracle.c) on seeded inputs.
+Bar: bit-exact for every integer array and for the float32 bit patterns, emission order included."""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _native(res, off, gen, k, **kw):
+    from pandelos_amd.pangene_native import PangeneNative
+    return PangeneNative.from_arrays(k, res, off, gen, **kw)
+
+
+@pytest.mark.parametrize("name", H.SMALL_CASES)
+def test_hip_matches_reference_fixture(name):
+    res, off, gen, k, fx = H.load_small(name)
+    nat = _native(res, off, gen, k)
+    c = nat.cost
+    assert (c.sequences, c.genomes) == (int(fx["sequences"]), int(fx["genomes"]))
+    assert c.total_cost == int(fx["total_cost"])
+    assert bool(c.hash_fallback) == bool(fx["hash_fallback"])
+    assert [nat.genome_cost(g) for g in range(c.genomes)] == [int(x) for x in fx["genome_cost"]]
+    H.assert_scores_equal_fixture(lambda g: nat.generate_scores_part(g).as_dict(), fx, c.genomes, name)
+
+
+@pytest.mark.parametrize("name", sorted(H.DIGESTS))
+def test_hip_matches_reference_digest(name):
+    res, off, gen, k, d = H.load_large(name)
+    nat = _native(res, off, gen, k)
+    assert nat.cost.total_cost == d["total_cost"]
+    assert [nat.genome_cost(g) for g in range(d["genomes"])] == d["genome_cost"]
+    H.assert_scores_match_digest(lambda g: nat.generate_scores_part(g).as_dict(), d, name)
+
+
+@pytest.mark.parametrize("name", ["synth_5x60x80_k3", "synth_5x60x80_k13", "synth_5x60x80_k16_hash", "low_complexity",
+                                  "q1_fold_same_gene_twice"])
+def test_dictionary_stage_matches_oracle(name):
+    """K-hist/K-rank/K-sort/K-rle: rank table, B^(k-1) and the (rank, gene, count) records."""
+    from oracle import binding as ob
+    res, off, gen, k, _ = H.load_small(name)
+    nat = _native(res, off, gen, k)
+    ora = ob.Oracle(res, off, gen, k)
+    tab, lm = nat.rank_table()
+    assert np.array_equal(tab, ora.rank_values) and lm == ora.last_multiplier
+    assert nat.cost.rank_base == ora.rank_base and nat.cost.kmer_occurrences == ora.kmer_occurrences
+    ranks, seqs, counts = nat.dictionary()
+    d = ora.dictionary()
+    # the oracle re-sorts the folded last group by gene (library.cpp:312-315); compare as (rank, gene)-sorted sets
+    o = np.lexsort((d["seq"], d["rank"]))
+    assert np.array_equal(ranks, d["rank"][o]) and np.array_equal(seqs, d["seq"][o]) and np.array_equal(counts, d["count"][o])
+    cost, kl = nat.sequence_costs()
+    assert np.array_equal(cost, ora.total_visited()) and np.array_equal(kl, ora.kseq_lengths())
+
+
+@pytest.mark.parametrize("shape,k", [
+    (dict(genomes=7, genes_per_genome=150, mean_len=120, sub_rate=0.12, seed=201), 3),
+    (dict(genomes=12, genes_per_genome=400, mean_len=150, sub_rate=0.2, seed=202), 4),
+    (dict(genomes=3, genes_per_genome=30, mean_len=2500, sub_rate=0.05, seed=203), 3),   # long genes: HBM-table rows
+    (dict(genomes=20, genes_per_genome=100, mean_len=60, sub_rate=0.3, seed=204), 2),    # k=2: everything matches everything
+])
+def test_hip_matches_oracle_on_random_sets(shape, k):
+    from oracle import binding as ob
+    from pandelos_amd.synth import make_gene_set
+    gs = make_gene_set(**shape)
+    nat = _native(gs.residues, gs.offsets, gs.genome_of, k)
+    ora = ob.Oracle(gs.residues, gs.offsets, gs.genome_of, k)
+    assert nat.cost.total_cost == ora.total_cost
+    for g in range(ora.genomes):
+        H.assert_scores_equal(nat.generate_scores_part(g).as_dict(), ora.scores(g), f"genome {g}")
+
+
+def test_errors_mirror_reference_behaviour():
+    from pandelos_amd import _lib
+    res, off, gen, _, _ = H.load_small("readme4_k2")
+    with pytest.raises(_lib.PdlError) as e:
+        _native(res, off, gen, 0)
+    assert e.value.code == _lib.PDL_ERR_KVALUE and "K value must be greater than 0" in str(e.value)
+    with pytest.raises(_lib.PdlError) as e:
+        _native(res, off, gen, 500)       # no gene is that long: empty dictionary
+    assert e.value.code == _lib.PDL_ERR_EMPTY
+
+
+def test_complexity_only_mode():
+    res, off, gen, k, fx = H.load_small("synth_5x60x80_k3")
+    nat = _native(res, off, gen, k, only_complexity=True)
+    assert nat.cost.total_cost == int(fx["total_cost"])
+    from pandelos_amd import _lib
+    with pytest.raises(_lib.PdlError):
+        nat.generate_scores_part(0)
+
+
+def test_genome_shard_scores_only_its_genomes():
+    res, off, gen, k, fx = H.load_small("synth_5x60x80_k3")
+    nat = _native(res, off, gen, k)
+    nat.set_genome_shard([1, 3])
+    for g in (1, 3):
+        got = nat.generate_scores_part(g).as_dict()
+        for f in H.FIELDS:
+            assert np.array_equal(H.raw(got[f]), fx[f"g{g}_{f}"]), (g, f)
+    from pandelos_amd import _lib
+    with pytest.raises(_lib.PdlError):
+        nat.generate_scores_part(0)
+    counts = nat.scores_counts()
+    assert counts[0] == 0 and counts[1] == len(fx["g1_scores"]) and counts[3] == len(fx["g3_scores"])
+
+
+def test_device_resident_inputs_via_torch():
+    import torch
+    from pandelos_amd.pangene_native import PangeneNative
+    res, off, gen, k, fx = H.load_small("synth_5x60x80_k3")
+    dev = torch.device("cuda:0")
+    pad = (-len(res)) % 16
+    t_res = torch.from_numpy(np.concatenate([res, np.zeros(pad + 16, np.uint8)])).to(dev)
+    t_off = torch.from_numpy(off.astype(np.int64)).to(dev)
+    t_gen = torch.from_numpy(gen.astype(np.int32)).to(dev)
+    torch.cuda.synchronize()
+    nat = PangeneNative.from_device(k, t_res.data_ptr(), t_off.data_ptr(), t_gen.data_ptr(), len(gen), len(res),
+                                    stream=torch.cuda.current_stream().cuda_stream, keepalive=(t_res, t_off, t_gen))
+    assert nat.cost.total_cost == int(fx["total_cost"])
+    H.assert_scores_equal_fixture(lambda g: nat.generate_scores_part(g).as_dict(), fx, nat.cost.genomes, "torch-resident")
+
+
+def test_canonical_order_flag_gives_same_cells_sorted_by_column():
+    from pandelos_amd import _lib
+    res, off, gen, k, fx = H.load_small("synth_5x60x80_k3")
+    nat = _native(res, off, gen, k, flags=_lib.PDL_FLAG_CANONICAL_ORDER)
+    for g in range(nat.cost.genomes):
+        got = nat.generate_scores_part(g).as_dict()
+        key = lambda r, c: (r.astype(np.int64) << 32) | c.astype(np.int64)
+        kg = key(got["row"], got["column"])
+        assert np.all(np.diff(kg) > 0)
+        o = np.argsort(key(fx[f"g{g}_row"], fx[f"g{g}_column"]))
+        assert np.array_equal(kg, key(fx[f"g{g}_row"], fx[f"g{g}_column"])[o])
+        assert np.array_equal(H.raw(got["scores"]), fx[f"g{g}_scores"][o])

@@ -91,7 +91,7 @@ struct pdl_ctx {
     bool preprocessed = false;
     bool only_complexity = false;
     uint32_t N = 0, G = 0;
-    uint64_t R = 0, M = 0, U = 0, Ushared = 0, NG = 0, P = 0, sum_kseq = 0, max_kseq = 0;
+    uint64_t R = 0, M = 0, U = 0, Ushared = 0, NG = 0, P = 0, sum_kseq = 0, max_kseq = 0, min_kseq = 0;
     RankParams rp{};
 
     // per sequence
@@ -130,6 +130,7 @@ struct pdl_ctx {
     std::vector<uint64_t> h_cell_off;         // [shard+1] first cell of each shard genome
     DevBuf task_rows;     // u32 [n_task_rows] gene id of each task position
     DevBuf task_lg;       // u32 [n_task_rows] shard-local genome index
+    DevBuf row_desc;      // uint4 [n_task_rows] {task position, gene, first range, ranges} in processing order
     DevBuf MS;            // f32 [n_task_rows][G]      max_genome_score rows
     DevBuf CM;            // f32 [shard][N]            max_genome_score_col per genome task
     DevBuf row_base, row_cnt, fin_off;   // u32 [n_task_rows(+1)]

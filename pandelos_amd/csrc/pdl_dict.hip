@@ -8,7 +8,7 @@
 //   K-sort    pdl_sort_pairs      stable LSD radix sort by rank              library.cpp:172-187,270-278
 //   K-rle     RecHead/RecScatter, k_build_records   dedup -> (rank,gene,count)   library.cpp:280-287
 //   K-groups  GroupHead scan, k_group_offsets, k_record_costs (+ the last-record fold)  library.cpp:297-335
-//   K-ranges  SharedFlag compaction, sort by gene, k_build_ranges, k_seq_offsets   library.cpp:318-326
+//   K-ranges  k_range_slots, seq_off scan, k_place_ranges, k_row_costs          library.cpp:318-327
 //   K-cost    k_genome_cost       per-genome and total lookups               library.cpp:337-350,535-538
 //
 // HBM layout after this stage (what the join reads):
@@ -248,46 +248,59 @@ struct GroupScatter {
 };
 __global__ void k_close_offsets(uint32_t *goff, const uint64_t *d_ng, uint32_t u_count) { goff[*d_ng] = u_count; }
 
-// total_visited (library.cpp:327): every record of a group with >= 2 records adds the group size
-// to its gene.  Also the flag of the compaction that follows.
+// total_visited (library.cpp:327) straight from the records: every record of a group with >= 2 records
+// adds the group size to its gene.  Only used in complexity-only mode (no range lists to sum over).
 __global__ __launch_bounds__(256) void k_record_costs(const uint2 *__restrict__ post, const uint32_t *__restrict__ gid,
                                                       const uint32_t *__restrict__ goff, uint32_t u_count,
-                                                      unsigned long long *__restrict__ cost) {
+                                                      unsigned long long *__restrict__ cost,
+                                                      unsigned long long *__restrict__ n_shared_records) {
+    __shared__ uint32_t s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
     const uint32_t u = blockIdx.x * 256 + threadIdx.x;
-    if (u >= u_count) return;
-    const uint32_t g = gid[u];
-    const uint32_t len = goff[g + 1] - goff[g];
-    if (len >= 2) atomicAdd(&cost[post[u].x], (unsigned long long) len);
+    bool shared = false;
+    if (u < u_count) {
+        const uint32_t g = gid[u];
+        const uint32_t len = goff[g + 1] - goff[g];
+        shared = len >= 2;
+        if (shared) atomicAdd(&cost[post[u].x], (unsigned long long) len);
+    }
+    const unsigned long long m = __ballot(shared);
+    if ((threadIdx.x & (PDL_WAVE - 1)) == 0 && m) atomicAdd(&s_cnt, (uint32_t) __popcll(m));
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt) atomicAdd(n_shared_records, (unsigned long long) s_cnt);   // one per workgroup
 }
 
+// K-ranges: the per-gene posting-range lists (kmers_ranges, library.cpp:318-326) as flat uint4
+// {group start, group length, own count, 0}, gene major.  The reference appends to each gene's list
+// while walking the groups in rank order; here that is a transposition of the dictionary:
+//   1. one pass in dictionary order packs every record of a shared group as a 16-byte tuple and
+//      compacts (gene, tuple index) pairs                                   [coalesced]
+//   2. a stable radix sort of the pairs by gene gives gene-major order, rank order inside a gene
+//   3. one gather of the 16-byte tuples through the sorted indices          [one random 16 B read each]
+// (Slot allocation with global atomics was measured 4x slower than the sort: device-scope atomics on
+// scattered counters run at the memory side on this chip.)
 struct SharedFlag {
     const uint32_t *gid; const uint32_t *goff;
     __device__ uint32_t operator()(uint64_t u) const { uint32_t g = gid[u]; return (goff[g + 1] - goff[g]) >= 2 ? 1u : 0u; }
 };
 struct SharedScatter {
-    const uint2 *post; uint32_t *key2; uint32_t *val2;
+    const uint2 *post; const uint32_t *gid; const uint32_t *goff;
+    uint32_t *key2; uint32_t *val2; uint4 *tuples;
     __device__ void operator()(uint64_t u, uint32_t f, uint32_t prefix) const {
-        if (f) { key2[prefix] = post[u].x; val2[prefix] = (uint32_t) u; }
+        if (!f) return;
+        const uint32_t g = gid[u];
+        const uint32_t gs = goff[g];
+        const uint2 po = post[u];
+        key2[prefix] = po.x; val2[prefix] = prefix;
+        tuples[prefix] = make_uint4(gs, goff[g + 1] - gs, po.y, 0u);
     }
 };
-struct SharedGroupFlag {   // groups with >= 2 records, for the statistics only
-    const uint32_t *goff;
-    __device__ uint32_t operator()(uint64_t g) const { return (goff[g + 1] - goff[g]) >= 2 ? 1u : 0u; }
-};
-struct NoApply { __device__ void operator()(uint64_t, uint32_t, uint32_t) const {} };
-
-// K-ranges: the per-gene posting-range lists (kmers_ranges, library.cpp:318-326) as flat uint4.
-__global__ __launch_bounds__(256) void k_build_ranges(const uint32_t *__restrict__ rec_sorted, const uint2 *__restrict__ post,
-                                                      const uint32_t *__restrict__ gid, const uint32_t *__restrict__ goff,
-                                                      uint32_t n, uint4 *__restrict__ ranges) {
+__global__ __launch_bounds__(256) void k_gather_ranges(const uint32_t *__restrict__ idx_sorted, const uint4 *__restrict__ tuples,
+                                                       uint32_t n, uint4 *__restrict__ ranges) {
     const uint32_t e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= n) return;
-    const uint32_t u = rec_sorted[e];
-    const uint32_t g = gid[u];
-    const uint32_t gs = goff[g];
-    ranges[e] = make_uint4(gs, goff[g + 1] - gs, post[u].y, 0u);
+    if (e < n) ranges[e] = tuples[idx_sorted[e]];
 }
-
 // seq_off[s] = first range of gene s in the gene-sorted list (lower bound), seq_off[N] = U'
 __global__ __launch_bounds__(256) void k_seq_offsets(const uint32_t *__restrict__ seq_sorted, uint32_t n, uint32_t n_seq,
                                                      uint32_t *__restrict__ seq_off) {
@@ -301,17 +314,49 @@ __global__ __launch_bounds__(256) void k_seq_offsets(const uint32_t *__restrict_
     seq_off[s] = lo;
 }
 
+// total_visited (library.cpp:327) = sum of the group lengths over a gene's ranges; one wave per gene.
+__global__ __launch_bounds__(256) void k_row_costs(const uint4 *__restrict__ ranges, const uint32_t *__restrict__ seq_off,
+                                                   uint32_t n_seq, unsigned long long *__restrict__ cost) {
+    const uint32_t s = blockIdx.x * (256 / PDL_WAVE) + threadIdx.x / PDL_WAVE;
+    if (s >= n_seq) return;
+    const uint32_t lane = threadIdx.x & (PDL_WAVE - 1);
+    unsigned long long sum = 0;
+    for (uint32_t e = seq_off[s] + lane; e < seq_off[s + 1]; e += PDL_WAVE) sum += ranges[e].y;
+#pragma unroll
+    for (int d = PDL_WAVE / 2; d > 0; d >>= 1) sum += __shfl_down(sum, d, PDL_WAVE);
+    if (lane == 0) cost[s] = sum;
+}
+
 // K-cost: per-genome cost (library.cpp:535-538); the total is their sum (library.cpp:337-349).
+// Genes of a genome are usually adjacent, so a wave first tries to add up as one.
 __global__ __launch_bounds__(256) void k_genome_cost(const unsigned long long *__restrict__ cost, const uint32_t *__restrict__ kseq_len,
                                                      const uint32_t *__restrict__ genome_of, uint32_t n_seq,
                                                      unsigned long long *__restrict__ genome_cost, unsigned long long *__restrict__ sum_kseq,
-                                                     unsigned long long *__restrict__ max_kseq) {
+                                                     unsigned long long *__restrict__ max_kseq, unsigned long long *__restrict__ min_kseq) {
     const uint32_t s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= n_seq) return;
-    unsigned long long c = cost[s];
-    if (c) atomicAdd(&genome_cost[genome_of[s]], c);
-    uint32_t kl = kseq_len[s];
-    if (kl) { atomicAdd(sum_kseq, (unsigned long long) kl); atomicMax(max_kseq, (unsigned long long) kl); }
+    const bool live = s < n_seq;
+    unsigned long long c = live ? cost[s] : 0ull;
+    unsigned long long kl = live ? (unsigned long long) kseq_len[s] : 0ull;
+    const uint32_t g = live ? genome_of[s] : 0xffffffffu;
+    const uint32_t g0 = __shfl(g, 0, PDL_WAVE);
+    const bool uniform = __all(g == g0 || !live);
+    unsigned long long ksum = kl, kmax = kl, csum = c, kmin = kl ? kl : ~0ull;
+#pragma unroll
+    for (int d = PDL_WAVE / 2; d > 0; d >>= 1) {
+        ksum += __shfl_down(ksum, d, PDL_WAVE);
+        unsigned long long o = __shfl_down(kmax, d, PDL_WAVE);
+        kmax = o > kmax ? o : kmax;
+        o = __shfl_down(kmin, d, PDL_WAVE);
+        kmin = o < kmin ? o : kmin;
+        csum += __shfl_down(csum, d, PDL_WAVE);
+    }
+    const uint32_t lane = threadIdx.x & (PDL_WAVE - 1);
+    if (lane == 0 && ksum) { atomicAdd(sum_kseq, ksum); atomicMax(max_kseq, kmax); atomicMin(min_kseq, kmin); }
+    if (uniform) {
+        if (lane == 0 && csum && g0 != 0xffffffffu) atomicAdd(&genome_cost[g0], csum);
+    } else if (live && c) {
+        atomicAdd(&genome_cost[g], c);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -320,6 +365,10 @@ static void dictionary_pipeline(pdl_ctx *c, bool only_complexity) {
     hipStream_t st = c->stream;
     const uint64_t M = c->M;
     uint64_t *d_scal = c->scalars.as<uint64_t>();
+
+    PDL_HIP(hipMemsetAsync(d_scal + 3, 0, 2 * sizeof(uint64_t), st));   // (unused), sum of kseq_lengths
+    PDL_HIP(hipMemsetAsync(d_scal + 7, 0, sizeof(uint64_t), st));       // max kseq_length
+    PDL_HIP(hipMemsetAsync(d_scal + 8, 0xff, sizeof(uint64_t), st));    // min non-zero kseq_length
 
     // K-rank
     ev_begin(c, EV_RANK);
@@ -370,65 +419,66 @@ static void dictionary_pipeline(pdl_ctx *c, bool only_complexity) {
     // K-groups
     scan_and_apply(c, U, GroupHeadFlag{ghead}, GroupScatter{c->gid.as<uint32_t>(), c->goff.as<uint32_t>()}, d_scal + 1);
     hipLaunchKernelGGL(k_close_offsets, dim3(1), dim3(1), 0, st, c->goff.as<uint32_t>(), d_scal + 1, Uu);
-    c->cost.alloc((size_t) c->N * sizeof(uint64_t));
-    PDL_HIP(hipMemsetAsync(c->cost.p, 0, (size_t) c->N * sizeof(uint64_t), st));
-    hipLaunchKernelGGL(k_record_costs, dim3(ublocks), dim3(256), 0, st, c->post.as<uint2>(), c->gid.as<uint32_t>(),
-                       c->goff.as<uint32_t>(), Uu, c->cost.as<unsigned long long>());
     PDL_HIP(hipGetLastError());
     ev_end(c, EV_DICT);
 
-    // K-cost
-    c->genome_cost.alloc((size_t) c->G * sizeof(uint64_t));
-    PDL_HIP(hipMemsetAsync(c->genome_cost.p, 0, (size_t) c->G * sizeof(uint64_t), st));
-    PDL_HIP(hipMemsetAsync(d_scal + 4, 0, sizeof(uint64_t), st));
-    PDL_HIP(hipMemsetAsync(d_scal + 7, 0, sizeof(uint64_t), st));
-    hipLaunchKernelGGL(k_genome_cost, dim3((c->N + 255) / 256), dim3(256), 0, st, c->cost.as<unsigned long long>(),
-                       c->kseq_len.as<uint32_t>(), c->d_gen, c->N, c->genome_cost.as<unsigned long long>(),
-                       reinterpret_cast<unsigned long long *>(d_scal + 4), reinterpret_cast<unsigned long long *>(d_scal + 7));
-
-    if (!only_complexity) {
-        // K-ranges: compact the records of shared groups, sort them by gene, expand to uint4 ranges
+    c->cost.alloc((size_t) c->N * sizeof(uint64_t));
+    if (only_complexity) {
+        PDL_HIP(hipMemsetAsync(c->cost.p, 0, (size_t) c->N * sizeof(uint64_t), st));
+        PDL_HIP(hipMemsetAsync(d_scal + 2, 0, sizeof(uint64_t), st));
+        hipLaunchKernelGGL(k_record_costs, dim3(ublocks), dim3(256), 0, st, c->post.as<uint2>(), c->gid.as<uint32_t>(),
+                           c->goff.as<uint32_t>(), Uu, c->cost.as<unsigned long long>(),
+                           reinterpret_cast<unsigned long long *>(d_scal + 2));
+    } else {
+        // K-ranges
         ev_begin(c, EV_SORT2);
-        // scratch: key2 goes to vals_a (M u32, free after the sort; keys_a's first U bytes hold ghead)
-        c->scratch.alloc(3 * U * sizeof(uint32_t));
+        // scratch layout: tuples uint4[U] | v2a u32[U] | k2b u32[U] | v2b u32[U]; key2 lives in vals_a (free after sort 1)
+        c->scratch.alloc(U * (sizeof(uint4) + 3 * sizeof(uint32_t)));
+        uint4 *tuples = c->scratch.as<uint4>();
         uint32_t *k2a = c->vals_a.as<uint32_t>();
-        uint32_t *v2a = c->scratch.as<uint32_t>();
-        uint32_t *k2b = c->scratch.as<uint32_t>() + U;
-        uint32_t *v2b = c->scratch.as<uint32_t>() + 2 * U;
+        uint32_t *v2a = reinterpret_cast<uint32_t *>(tuples + U);
+        uint32_t *k2b = v2a + U;
+        uint32_t *v2b = k2b + U;
         scan_and_apply(c, U, SharedFlag{c->gid.as<uint32_t>(), c->goff.as<uint32_t>()},
-                       SharedScatter{c->post.as<uint2>(), k2a, v2a}, d_scal + 2);
+                       SharedScatter{c->post.as<uint2>(), c->gid.as<uint32_t>(), c->goff.as<uint32_t>(), k2a, v2a, tuples}, d_scal + 2);
         uint64_t Us = 0;
         PDL_HIP(hipMemcpyAsync(&Us, d_scal + 2, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
         PDL_HIP(hipStreamSynchronize(st));
-        c->Ushared = Us;
         const uint32_t seq_bits = std::max<uint32_t>(1, bit_length64(c->N ? c->N - 1 : 0));
         pdl_sort_pairs<uint32_t>(c, k2a, k2b, v2a, v2b, Us, seq_bits);     // sorted pairs now in (k2b, v2b)
         ev_end(c, EV_SORT2);
 
         ev_begin(c, EV_RANGES);
-        c->ranges.alloc(Us * sizeof(uint4));
+        c->ranges.alloc(std::max<uint64_t>(Us, 1) * sizeof(uint4));
         c->seq_off.alloc(((size_t) c->N + 1) * sizeof(uint32_t));
-        if (Us) hipLaunchKernelGGL(k_build_ranges, dim3(((uint32_t) Us + 255) / 256), dim3(256), 0, st, v2b, c->post.as<uint2>(),
-                                   c->gid.as<uint32_t>(), c->goff.as<uint32_t>(), (uint32_t) Us, c->ranges.as<uint4>());
+        if (Us) hipLaunchKernelGGL(k_gather_ranges, dim3(((uint32_t) Us + 255) / 256), dim3(256), 0, st, v2b, tuples, (uint32_t) Us,
+                                   c->ranges.as<uint4>());
         hipLaunchKernelGGL(k_seq_offsets, dim3((c->N + 1 + 255) / 256), dim3(256), 0, st, k2b, (uint32_t) Us, c->N, c->seq_off.as<uint32_t>());
+        hipLaunchKernelGGL(k_row_costs, dim3((c->N + 3) / 4), dim3(256), 0, st, c->ranges.as<uint4>(), c->seq_off.as<uint32_t>(),
+                           c->N, c->cost.as<unsigned long long>());
         PDL_HIP(hipGetLastError());
         ev_end(c, EV_RANGES);
     }
 
-    // statistics: number of shared groups
-    uint64_t NGall = 0;
-    PDL_HIP(hipMemcpyAsync(&NGall, d_scal + 1, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    PDL_HIP(hipStreamSynchronize(st));
-    scan_and_apply(c, NGall, SharedGroupFlag{c->goff.as<uint32_t>()}, NoApply{}, d_scal + 3);
+    // K-cost
+    c->genome_cost.alloc((size_t) c->G * sizeof(uint64_t));
+    PDL_HIP(hipMemsetAsync(c->genome_cost.p, 0, (size_t) c->G * sizeof(uint64_t), st));
+    hipLaunchKernelGGL(k_genome_cost, dim3((c->N + 255) / 256), dim3(256), 0, st, c->cost.as<unsigned long long>(),
+                       c->kseq_len.as<uint32_t>(), c->d_gen, c->N, c->genome_cost.as<unsigned long long>(),
+                       reinterpret_cast<unsigned long long *>(d_scal + 4), reinterpret_cast<unsigned long long *>(d_scal + 7),
+                       reinterpret_cast<unsigned long long *>(d_scal + 8));
+
     c->h_genome_cost.assign(c->G, 0);
     PDL_HIP(hipMemcpyAsync(c->h_genome_cost.data(), c->genome_cost.p, (size_t) c->G * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    uint64_t tail[2] = {0, 0};
-    PDL_HIP(hipMemcpyAsync(tail, d_scal + 3, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    uint64_t tail[9] = {0};
+    PDL_HIP(hipMemcpyAsync(tail, d_scal, 9 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     PDL_HIP(hipStreamSynchronize(st));
-    c->NG = tail[0];
-    c->sum_kseq = tail[1];
-    PDL_HIP(hipMemcpyAsync(&c->max_kseq, d_scal + 7, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    PDL_HIP(hipStreamSynchronize(st));
+    c->Ushared = tail[2];
+    // every record outside the shared groups is a group of its own: shared groups = all groups - singletons
+    c->NG = tail[1] - (c->U - c->Ushared);
+    c->sum_kseq = tail[4];
+    c->max_kseq = tail[7];
+    c->min_kseq = tail[8] == ~0ull ? 1 : tail[8];
     c->P = 0;
     for (uint64_t v : c->h_genome_cost) c->P += v;
 }

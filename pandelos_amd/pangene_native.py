@@ -43,12 +43,18 @@ class PangeneNative:
         """Device-resident inputs (raw device pointers, e.g. ``tensor.data_ptr()``)."""
         self = cls.__new__(cls)
         self._open(device, stream, flags)
+        self.preprocess_device(k, d_residues, d_offsets, d_genome_of, n_sequences, n_residues, only_complexity, keepalive)
+        return self
+
+    def preprocess_device(self, k, d_residues: int, d_offsets: int, d_genome_of: int, n_sequences: int,
+                          n_residues: int, only_complexity=False, keepalive=None):
+        """(Re)run preprocessSequences on this context from device-resident inputs; like the reference's
+        entry point it resets all state of the context first (library.cpp:192).  Work buffers are reused."""
         self._keep = keepalive
         self.cost = _lib.PdlCost()
         rc = self._lib.pdl_preprocess_device(self._ctx, d_residues, d_offsets, d_genome_of, n_sequences, n_residues,
                                              int(k), int(only_complexity), C.byref(self.cost))
         self._check(rc)
-        return self
 
     @staticmethod
     def print_complexity(k: int, data: PangeneIData) -> "PangeneNative":

@@ -136,3 +136,27 @@ def test_canonical_order_flag_gives_same_cells_sorted_by_column():
         o = np.argsort(key(fx[f"g{g}_row"], fx[f"g{g}_column"]))
         assert np.array_equal(kg, key(fx[f"g{g}_row"], fx[f"g{g}_column"])[o])
         assert np.array_equal(H.raw(got["scores"]), fx[f"g{g}_scores"][o])
+
+
+@pytest.mark.parametrize("name", ["synth_5x60x80_k3", "low_complexity", "q1_fold_same_gene_twice", "readme4_k1"])
+def test_hbm_table_path_matches_fixture(name, monkeypatch):
+    """Rows whose candidate set does not fit the LDS table are redone by k_join_hbm.  A deliberately tiny
+    LDS table (PDL_JOIN_TABLE_BITS=9: 512 slots, 64 ranges staged per batch) exercises the multi-batch staging
+    and, where a row has more than 384 candidates, that path."""
+    monkeypatch.setenv("PDL_JOIN_TABLE_BITS", "9")
+    res, off, gen, k, fx = H.load_small(name)
+    nat = _native(res, off, gen, k)
+    H.assert_scores_equal_fixture(lambda g: nat.generate_scores_part(g).as_dict(), fx, nat.cost.genomes, name)
+
+
+def test_hbm_table_path_matches_oracle_on_dense_set(monkeypatch):
+    """k=2 on 1500 genes: every gene shares k-mers with every other one (candidate sets ~ N)."""
+    from oracle import binding as ob
+    from pandelos_amd.synth import make_gene_set
+    monkeypatch.setenv("PDL_JOIN_TABLE_BITS", "9")
+    gs = make_gene_set(genomes=10, genes_per_genome=150, mean_len=60, sub_rate=0.3, seed=205)
+    nat = _native(gs.residues, gs.offsets, gs.genome_of, 2)
+    ora = ob.Oracle(gs.residues, gs.offsets, gs.genome_of, 2)
+    for g in range(ora.genomes):
+        H.assert_scores_equal(nat.generate_scores_part(g).as_dict(), ora.scores(g), f"genome {g}")
+    assert nat.timings()["overflow_rows"] > 1000

@@ -94,9 +94,9 @@ typedef struct {
     uint64_t emitted_cells;        /* Z over the genomes scored by this context */
     uint64_t scored_rows;          /* rows (genes) scored by this context */
     uint64_t scored_lookups;       /* P restricted to those rows */
-    uint64_t overflow_rows;        /* rows that left the LDS table for the HBM table */
+    uint64_t overflow_rows;        /* rows that left the LDS tables for the HBM table (tier 3) */
     uint32_t join_launches;
-    uint32_t reserved;
+    uint32_t tier2_rows;           /* rows the filtered small-table tier handed to the big LDS table */
 } pdl_timings;
 
 PDL_API pdl_ctx *pdl_create(const pdl_config *cfg /* may be NULL */);

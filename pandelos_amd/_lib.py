@@ -52,7 +52,7 @@ class PdlTimings(C.Structure):
                 ("join_overflow_ms", C.c_float), ("order_ms", C.c_float), ("preprocess_total_ms", C.c_float),
                 ("score_total_ms", C.c_float), ("emitted_cells", C.c_uint64), ("scored_rows", C.c_uint64),
                 ("scored_lookups", C.c_uint64), ("overflow_rows", C.c_uint64), ("join_launches", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("tier2_rows", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}

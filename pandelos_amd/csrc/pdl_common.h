@@ -141,6 +141,8 @@ struct pdl_ctx {
     DevBuf join_ctr;      // u32 [8] cursors/counters of the join
     DevBuf overflow_rows; // u32 [n_task_rows]
     DevBuf glb_table;     // HBM tables of the overflow pass
+    bool glb_clean = false;   // all-zero (k_join_hbm leaves them that way)
+    DevBuf row_desc2;     // descriptors of the rows handed from tier 1 to tier 2
 
     pdl_timings tm{};
     EventPair ev[12];

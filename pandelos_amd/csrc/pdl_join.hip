@@ -45,16 +45,20 @@ struct JoinArgs {
     const uint32_t *work;          // task positions to process (k_join_hbm: the overflow list)
     const uint4 *desc;             // k_join_lds: {task position, gene, first range, ranges} per work item
     uint32_t n_work;
+    const uint32_t *n_work_ptr;    // when set: number of work items, produced on the device by the previous tier
     uint32_t N, G, k;
     uint32_t min_kseq;             // smallest non-zero kseq_length of the dataset (finalize pre-filter)
     uint32_t canonical;            // PDL_FLAG_CANONICAL_ORDER: no first-touch tracking
+    uint32_t debug;                // PDL_JOIN_DEBUG (timing experiments only): 1 skip table ops, 2 skip posting loads, 4 skip finalize
     float *MS;                     // [n_task_rows][G]
     float *CM;                     // [shard][N]
     uint32_t *row_base, *row_cnt;  // [n_task_rows]
     float *st_score, *st_perc, *st_tr;
     uint32_t *st_col, *st_first;
     unsigned long long st_cap;
-    uint32_t *work_cursor;         // persistent-workgroup row dispenser
+    uint32_t *work_cursor;         // persistent-workgroup row dispenser (one atomic hands out `work_batch` items:
+                                   // a single device-scope word serves only ~90 dequeues/us)
+    uint32_t work_batch;
     unsigned long long *cell_cursor;
     uint32_t *overflow_count;
     uint32_t *error_count;         // internal consistency violations (must stay 0)
@@ -63,6 +67,14 @@ struct JoinArgs {
     unsigned long long *hbm_acc;
     uint32_t *hbm_u32;
 };
+
+// smallest integer n with (float) n / denom >= threshold (the quotient is monotone in n; n < 2^24 is exact in float)
+__device__ __forceinline__ uint32_t min_numerator(float threshold, float denom) {
+    uint32_t n = (uint32_t) (threshold * denom);
+    n = n > 2 ? n - 2 : 0;
+    while ((float) (int) n / denom < threshold) n++;
+    return n;
+}
 
 // finalize one candidate (library.cpp:494-502); returns score (0 when not emitted)
 __device__ __forceinline__ float finalize_cell(unsigned long long acc, uint32_t my_kcnt, uint32_t other_kcnt, float threshold,
@@ -78,78 +90,197 @@ __device__ __forceinline__ float finalize_cell(unsigned long long acc, uint32_t 
 }
 
 // ------------------------------------------------------------------------------------------------
-// K-join (LDS table).  Persistent workgroups pull rows from a global cursor.
+// K-join (LDS table).  Persistent workgroups pull rows (work items) from a global cursor.
 //
 // Per row:
 //   stage     the row's ranges are copied to LDS (coalesced 16-byte loads) with the exclusive prefix of
 //             their lengths: the row's lookups become one flat index space [0, L)
 //   lookups   lane t handles flat indices t, t+T, ...; four at a time: four binary searches in the LDS
-//             prefix (independent, interleaved by the compiler), then four 8-byte posting loads in flight,
-//             then per posting one 8-byte LDS read (key, first) and one 64-bit LDS atomic add
+//             prefix (independent, interleaved by the compiler), then four 8-byte posting loads in flight
 //   finalize  touched slots only (the reference's colored_cells); candidates that cannot pass the
-//             validity threshold are dropped before their column's k-mer count is fetched
-//   emit      cells go to a per-workgroup chunk of the staging area; the emitted-slot list overwrites the
-//             touched list in place (a round's slots are in registers before anything is overwritten)
+//             validity threshold are dropped before their column's k-mer count is fetched; cells are
+//             written where they are decided, into a staging chunk owned by the workgroup
 // The table is cleared once per workgroup; afterwards every slot is reset by whoever consumes it.
+//
+// Two flavours of the lookup phase:
+//   FILTER = false  one pass: every posting is probed/inserted and added (1 LDS read + 1 64-bit LDS atomic).
+//                   The table must hold every column that shares a k-mer with the row, so it is big
+//                   (8192 slots, 1 workgroup per CU).
+//   FILTER = true   "seen twice" filter.  A column that shares exactly ONE k-mer occurrence pair with the
+//                   row (one lookup, both counts 1) has inter = perc_cnt = tr_cnt = 1 and is valid only if
+//                   1/K_row >= thr or 1/K_col >= thr, i.e. K <= 2k (library.cpp:497-500).  When the row and
+//                   every gene of the dataset have more than 2k k-mers such a column can never be emitted,
+//                   and on k-mer-rich data these are ~95 % of all columns a row touches.  Pass 1 sets a bit
+//                   per (hashed) column in a 64-Kbit LDS bitmap and inserts the column key only when its bit
+//                   was already set (second sighting; hash collisions only add keys) or the lookup is heavy
+//                   (a count >= 2); pass 2 re-walks the lookups and adds the contributions of the columns
+//                   that have a key.  Sums of inserted columns are complete and exact; dropped columns are
+//                   exactly the ones the reference would not emit.  The table shrinks ~20x, so 5-8
+//                   workgroups (rows) are resident per CU instead of one.
+// Rows whose keys do not fit are appended to an overflow list for the next tier.
 // ------------------------------------------------------------------------------------------------
-template <int HT_BITS_, int T_>
+constexpr uint32_t BM_WORDS = 2048;                        // 65536-bit "seen once" bitmap
+
+template <int HT_BITS_, int T_, bool FILTER>
 struct JoinCfg {
     static constexpr uint32_t HT = 1u << HT_BITS_;
-    static constexpr uint32_t LIMIT = HT / 4 * 3;          // rows with more candidates go to the HBM table
+    static constexpr uint32_t LIMIT = FILTER ? HT - T_ - HT / 8 : HT / 4 * 3;   // more keys than this: next tier
     static constexpr uint32_t TOUCH_CAP = LIMIT + T_;      // < HT: the probe loop always finds a free slot
-    static constexpr uint32_t RB = T_;                     // ranges staged per batch
+    static constexpr uint32_t RPT = FILTER ? 2 : 1;        // ranges staged per thread and batch
+    static constexpr uint32_t RB = RPT * T_;
     static_assert(TOUCH_CAP < HT, "table must never fill up");
+    static_assert(TOUCH_CAP <= CELL_CHUNK, "a staging chunk must hold any row");
 };
 
-template <int HT_BITS_, int T_>
+template <int HT_BITS_, int T_, bool FILTER>
 __global__ __launch_bounds__(T_) void k_join_lds(JoinArgs a) {
-    using Cfg = JoinCfg<HT_BITS_, T_>;
-    constexpr uint32_t HT = Cfg::HT, LIMIT = Cfg::LIMIT, TOUCH_CAP = Cfg::TOUCH_CAP, RB = Cfg::RB;
+    using Cfg = JoinCfg<HT_BITS_, T_, FILTER>;
+    constexpr uint32_t HT = Cfg::HT, LIMIT = Cfg::LIMIT, TOUCH_CAP = Cfg::TOUCH_CAP, RB = Cfg::RB, RPT = Cfg::RPT;
     constexpr int T = T_;
     __shared__ unsigned long long s_acc[HT];
     __shared__ uint2 s_kf[HT];                       // {column id, 0xffffffff - smallest group start that touched it}
+    __shared__ uint32_t s_bm[FILTER ? BM_WORDS : 1];
     __shared__ uint16_t s_touched[TOUCH_CAP];
-    __shared__ uint32_t s_gs[RB], s_mc[RB], s_cum[RB + 1];
+    __shared__ uint2 s_gm[RB + 1];                   // staged ranges: {group start, own count}
+    __shared__ uint32_t s_cum[RB + 66];               // exclusive prefix of their lengths, 0xffffffff beyond the batch
     __shared__ uint32_t s_wave[17];
-    __shared__ uint32_t s_ntouched, s_nemit, s_overflow, s_next;
+    __shared__ uint2 s_wstart[T_ / PDL_WAVE];          // per wave: {range holding the first lookup of its segment, that range's start}
+    __shared__ uint32_t s_ntouched, s_nemit, s_overflow, s_next, s_batch_end;
     __shared__ uint4 s_desc;
     __shared__ unsigned long long s_base, s_chunk_next, s_chunk_end;
-    static_assert(TOUCH_CAP <= CELL_CHUNK, "a chunk must hold any row");
 
     const uint32_t tid = threadIdx.x;
+    const uint32_t n_work = a.n_work_ptr ? *a.n_work_ptr : a.n_work;
     for (uint32_t i = tid; i < HT; i += T) { s_kf[i] = make_uint2(EMPTY_KEY, 0u); s_acc[i] = 0; }
+    for (uint32_t i = RB + tid; i < RB + 66; i += T) s_cum[i] = 0xffffffffu;
     if (tid == 0) {
+        s_gm[RB] = make_uint2(0u, 0u);
         s_ntouched = 0; s_nemit = 0; s_overflow = 0; s_chunk_next = 0; s_chunk_end = 0;
-        const uint32_t w0 = atomicAdd(a.work_cursor, 1u);
-        s_next = w0;
-        if (w0 < a.n_work) s_desc = a.desc[w0];
+        const uint32_t w0 = atomicAdd(a.work_cursor, a.work_batch);
+        s_next = w0; s_batch_end = w0 + a.work_batch;
+        if (w0 < n_work) s_desc = a.desc[w0];
     }
     const float threshold = 1.0f / (2.0f * (float) a.k);
-    const float f_min_kseq = (float) (int) a.min_kseq;
+    const uint32_t tc_min = min_numerator(threshold, (float) (int) a.min_kseq);
     const bool track_first = a.canonical == 0;
 
-    auto accumulate = [&](uint32_t c, uint32_t cc, uint32_t mc, uint32_t finv) {
+    // insert column c if it has no slot yet; returns the slot (table can never be full, see TOUCH_CAP)
+    auto find_or_insert = [&](uint32_t c, uint32_t &seen_first) -> uint32_t {
         uint32_t slot = (c * 2654435761u) >> (32 - HT_BITS_);
-        uint32_t seen_first;
         for (;;) {
             const uint2 kf = s_kf[slot];
             seen_first = kf.y;
-            if (kf.x == c) break;
+            if (kf.x == c) return slot;
             if (kf.x == EMPTY_KEY) {
                 const uint32_t old = atomicCAS(&s_kf[slot].x, EMPTY_KEY, c);
                 if (old == EMPTY_KEY) {
                     const uint32_t idx = atomicAdd(&s_ntouched, 1u);
                     if (idx < TOUCH_CAP) s_touched[idx] = (uint16_t) slot;
                     if (idx >= LIMIT) s_overflow = 1;
-                    break;
+                    return slot;
                 }
-                if (old == c) break;
+                if (old == c) return slot;
             }
             slot = (slot + 1) & (HT - 1);
         }
+    };
+    auto add_to = [&](uint32_t slot, uint32_t seen_first, uint32_t cc, uint32_t mc, uint32_t finv) {
         if (track_first && seen_first < finv) atomicMax(&s_kf[slot].y, finv);
         const unsigned long long add = (unsigned long long) min(cc, mc) | ((unsigned long long) mc << 21) | ((unsigned long long) cc << 42);
         atomicAdd(&s_acc[slot], add);
+    };
+    // stage ranges [e0 + b0, e0 + b0 + nb) and return the number of lookups they hold
+    auto stage = [&](uint32_t e0, uint32_t b0, uint32_t nb) -> uint32_t {
+        uint32_t len[RPT], sum = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < RPT; j++) {
+            const uint32_t i = tid * RPT + j;
+            len[j] = 0;
+            if (i < nb) {
+                const uint4 rg = a.ranges[e0 + b0 + i];       // {group start, length, own count}
+                s_gm[i] = make_uint2(rg.x, rg.z); len[j] = rg.y;
+            }
+            sum += len[j];
+        }
+        uint32_t total;
+        uint32_t ex = block_exclusive_scan_u32(sum, s_wave, total);
+        // every wave walks a contiguous segment of the flat lookup space: segment w starts at lookup w * seg
+        constexpr uint32_t NW = T / PDL_WAVE;
+        const uint32_t chunks = (total + PDL_WAVE - 1) / PDL_WAVE;
+        const uint32_t seg = ((chunks + NW - 1) / NW) * PDL_WAVE;
+#pragma unroll
+        for (uint32_t j = 0; j < RPT; j++) {
+            const uint32_t i = tid * RPT + j;
+            s_cum[i] = i < nb ? ex : 0xffffffffu;
+            if (len[j]) {                                    // the range that holds a segment's first lookup registers itself
+                const uint32_t w_lo = seg ? (ex + seg - 1) / seg : 0;        // first w with w * seg >= ex
+                for (uint32_t w = w_lo; w < NW && w * seg < ex + len[j]; w++) s_wstart[w] = make_uint2(i, ex);
+            }
+            ex += len[j];
+        }
+        if (tid == 0) s_cum[RB] = 0xffffffffu;
+        __syncthreads();
+        if (tid == 0) s_cum[nb] = total;                     // > every flat index
+        __syncthreads();
+        return total;
+    };
+    // Walk the staged lookups; fn(posting, {group start, own count}).  Every wave owns a contiguous segment of
+    // the flat lookup space and takes it 64 lookups (one per lane) at a time, four such chunks in flight.  The
+    // range of each lane's lookup comes from ONE coalesced LDS read per chunk: lane l reads the start of range
+    // rs+1+l (rs = range holding the chunk's first lookup, carried in scalar registers); the starts that fall
+    // inside the chunk are turned into a 64-bit boundary mask with scalar ops, and a lane's range is rs +
+    // popcount(boundaries at or below the lane), its offset the distance to the last such boundary.
+    auto walk = [&](uint32_t total, auto &&fn) {
+        if (a.debug & 8) return;
+        constexpr uint32_t NW = T / PDL_WAVE;
+        const uint32_t lane = tid & (PDL_WAVE - 1), wave = tid / PDL_WAVE;
+        const uint32_t chunks = (total + PDL_WAVE - 1) / PDL_WAVE;
+        const uint32_t cpw = (chunks + NW - 1) / NW;
+        uint32_t ch = wave * cpw;
+        const uint32_t ch_end = min(chunks, ch + cpw);
+        if (ch >= ch_end) return;
+        const uint2 ws = s_wstart[wave];
+        uint32_t rs = __builtin_amdgcn_readfirstlane(ws.x);        // wave-uniform: range holding lookup ch * 64
+        uint32_t cum_rs = __builtin_amdgcn_readfirstlane(ws.y);    // and its first flat index
+        for (; ch < ch_end; ch += 4) {
+            if (*(volatile uint32_t *) &s_overflow) break;
+            uint2 gm[4], po[4];
+            uint32_t adr[4];
+            bool live[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                live[u] = false;
+                if (ch + u < ch_end) {                   // wave-uniform: all 64 lanes are active in here
+                    const uint32_t f0 = (ch + u) * PDL_WAVE, f = f0 + lane;
+                    const uint32_t v = s_cum[rs + 1 + lane];            // starts of the following ranges (all > f0)
+                    const bool inside = v < f0 + PDL_WAVE;              // a prefix of the lanes (starts ascend)
+                    // scatter "a range starts here" to the lane at that position: LDS crossbar, no memory touched.
+                    // Lanes without a start inside the chunk send 0 to lane 0, which is never a start position.
+                    const int recv = __builtin_amdgcn_ds_permute((int) ((inside ? v - f0 : 0u) << 2), inside ? 1 : 0);
+                    const unsigned long long m = __ballot(recv != 0);
+                    const uint32_t w = (uint32_t) __popcll(__ballot(inside));
+                    const unsigned long long below = m & ((2ull << lane) - 1ull);
+                    const uint32_t r = rs + (uint32_t) __popcll(below);
+                    const uint32_t off = below ? lane - (63u - (uint32_t) __clzll((long long) below)) : f - cum_rs;
+                    live[u] = f < total;
+                    gm[u] = s_gm[r];
+                    adr[u] = gm[u].x + off;
+                    // keep the invariant "rs holds the first lookup of the next chunk": a range may start exactly there
+                    const uint32_t nextb = __builtin_amdgcn_readlane(v, w);      // w <= 32: groups have >= 2 records
+                    if (nextb == f0 + PDL_WAVE) { rs += w + 1; cum_rs = nextb; }
+                    else if (w) { cum_rs = __builtin_amdgcn_readlane(v, w - 1); rs += w; }
+                }
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++)
+                if (live[u]) po[u] = (a.debug & 2) ? make_uint2(adr[u] % a.N, 1u) : a.post[adr[u]];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++)
+                if (live[u] && !*(volatile uint32_t *) &s_overflow) {  // <= 1 insertion per lane after the flag: TOUCH_CAP < HT holds
+                    if (a.debug & 1) { if (po[u].x == 0xfffffff0u) s_overflow = 1; }
+                    else fn(po[u], gm[u]);
+                }
+        }
     };
 
     for (;;) {
@@ -157,63 +288,73 @@ __global__ __launch_bounds__(T_) void k_join_lds(JoinArgs a) {
         const uint32_t wi = s_next;
         const uint4 d = s_desc;
         __syncthreads();
-        if (wi >= a.n_work) break;                       // uniform: every wave leaves here
+        if (wi >= n_work) break;                         // uniform: every wave leaves here
         // the next row's ticket and descriptor are fetched now and parked in registers of lane 0 until the
         // end of this row, so the row after this one starts without a dependent global load
         uint32_t next_reg = 0;
         uint4 next_desc = make_uint4(0, 0, 0, 0);
         if (tid == 0) {
-            next_reg = atomicAdd(a.work_cursor, 1u);
-            if (next_reg < a.n_work) next_desc = a.desc[next_reg];
+            next_reg = wi + 1;
+            if (next_reg >= s_batch_end) {               // batch used up: take the next one
+                next_reg = atomicAdd(a.work_cursor, a.work_batch);
+                s_batch_end = next_reg + a.work_batch;
+            }
+            if (next_reg < n_work) next_desc = a.desc[next_reg];
         }
-        const uint32_t p = d.x, r = d.y, e0 = d.z, nr = d.w;
+        const uint32_t p = d.x, r = d.y, e0 = d.z, nr = (a.debug & 16) ? 0u : d.w;
         if (nr == 0) {                                   // gene shares no k-mer group: no candidates
             if (tid == 0) { a.row_base[p] = 0; a.row_cnt[p] = 0; s_next = next_reg; s_desc = next_desc; }
             continue;
         }
-        // ---- accumulate (library.cpp:461-479) ------------------------------------------------------
-        for (uint32_t b0 = 0; b0 < nr; b0 += RB) {
-            const uint32_t nb = min(RB, nr - b0);
-            uint32_t len = 0;
-            if (tid < nb) {
-                const uint4 rg = a.ranges[e0 + b0 + tid];     // {group start, length, own count}
-                s_gs[tid] = rg.x; s_mc[tid] = rg.z; len = rg.y;
+        const uint32_t my_kcnt = a.kseq_len[r];
+        // ---- lookups (library.cpp:461-479) -----------------------------------------------------------
+        if constexpr (!FILTER) {
+            for (uint32_t b0 = 0; b0 < nr; b0 += RB) {
+                const uint32_t total = stage(e0, b0, min(RB, nr - b0));
+                walk(total, [&](uint2 po, uint2 gm) {
+                    uint32_t seen;
+                    const uint32_t slot = find_or_insert(po.x, seen);
+                    add_to(slot, seen, po.y, gm.y, 0xffffffffu - gm.x);
+                });
+                __syncthreads();
             }
-            uint32_t total;
-            const uint32_t ex = block_exclusive_scan_u32(len, s_wave, total);
-            s_cum[tid] = tid < nb ? ex : 0xffffffffu;
-            if (tid == 0) s_cum[RB] = 0xffffffffu;
-            __syncthreads();
-            if (tid == 0) s_cum[nb] = total;                 // > every flat index
-            __syncthreads();
-            for (uint32_t f0 = tid; f0 < total; f0 += 4 * T) {
-                if (*(volatile uint32_t *) &s_overflow) break;
-                uint32_t rr[4], ff[4];
-                uint2 po[4];
-                bool live[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    ff[u] = f0 + u * T;
-                    live[u] = ff[u] < total;
-                    uint32_t pos = 0;                        // largest pos with s_cum[pos] <= f
-#pragma unroll
-                    for (uint32_t step = RB / 2; step >= 1; step >>= 1)
-                        if (s_cum[pos + step] <= ff[u]) pos += step;
-                    rr[u] = pos;
+        } else {
+            // single-sighting columns may be dropped only if nobody involved has <= 2k k-mers
+            const bool filter_on = my_kcnt > 2 * a.k && a.min_kseq > 2 * a.k;
+            for (uint32_t i = tid; i < BM_WORDS / 4; i += T) reinterpret_cast<uint4 *>(s_bm)[i] = make_uint4(0, 0, 0, 0);
+            uint32_t total = 0;
+            for (uint32_t b0 = 0; b0 < nr; b0 += RB) {       // pass 1: which columns need a slot
+                total = stage(e0, b0, min(RB, nr - b0));     // (its barriers also cover the bitmap clear)
+                walk(total, [&](uint2 po, uint2 gm) {
+                    bool ins = !filter_on || max(po.y, gm.y) >= 2;
+                    if (!ins) {
+                        const uint32_t h = (po.x * 0x9E3779B1u) >> 16;
+                        const uint32_t bit = 1u << (h & 31);
+                        ins = (atomicOr(&s_bm[h >> 5], bit) & bit) != 0;
+                    }
+                    if (ins) { uint32_t seen; (void) find_or_insert(po.x, seen); }
+                });
+                __syncthreads();
+            }
+            if (!s_overflow) {
+                for (uint32_t b0 = 0; b0 < nr; b0 += RB) {   // pass 2: add every contribution of the kept columns
+                    if (nr > RB) total = stage(e0, b0, min(RB, nr - b0));   // single batch: still staged
+                    walk(total, [&](uint2 po, uint2 gm) {
+                        uint32_t slot = (po.x * 2654435761u) >> (32 - HT_BITS_);
+                        for (;;) {
+                            const uint2 kf = s_kf[slot];
+                            if (kf.x == po.x) { add_to(slot, kf.y, po.y, gm.y, 0xffffffffu - gm.x); break; }
+                            if (kf.x == EMPTY_KEY) break;    // column was seen once only
+                            slot = (slot + 1) & (HT - 1);
+                        }
+                    });
+                    __syncthreads();
                 }
-#pragma unroll
-                for (int u = 0; u < 4; u++)
-                    if (live[u]) po[u] = a.post[s_gs[rr[u]] + (ff[u] - s_cum[rr[u]])];
-#pragma unroll
-                for (int u = 0; u < 4; u++)
-                    if (live[u] && !*(volatile uint32_t *) &s_overflow)   // <= 1 insertion per lane after the flag: TOUCH_CAP < HT holds
-                        accumulate(po[u].x, po[u].y, s_mc[rr[u]], 0xffffffffu - s_gs[rr[u]]);
             }
-            __syncthreads();
         }
         const uint32_t ntouched = min(s_ntouched, TOUCH_CAP);
         if (s_overflow) {
-            // candidate set too large for LDS: hand the row to the HBM kernel, wipe the table
+            // too many keys for this table: hand the row to the next tier, wipe the table
             if (tid == 0) a.overflow_rows[atomicAdd(a.overflow_count, 1u)] = p;
             __syncthreads();
             for (uint32_t i = tid; i < HT; i += T) { s_kf[i] = make_uint2(EMPTY_KEY, 0u); s_acc[i] = 0; }
@@ -232,8 +373,7 @@ __global__ __launch_bounds__(T_) void k_join_lds(JoinArgs a) {
             }
             s_base = nx;
         }
-        const uint32_t my_kcnt = a.kseq_len[r];
-        const float f_my = (float) (int) my_kcnt;
+        const uint32_t pc_min = min_numerator(threshold, (float) (int) my_kcnt);
         float *ms_row = a.MS + (size_t) p * a.G;
         float *cm_row = a.CM + (size_t) a.task_lg[p] * a.N;
         __syncthreads();
@@ -245,14 +385,14 @@ __global__ __launch_bounds__(T_) void k_join_lds(JoinArgs a) {
             const uint32_t c = kf.x;
             const unsigned long long acc = s_acc[slot];
             s_kf[slot] = make_uint2(EMPTY_KEY, 0u); s_acc[slot] = 0;        // slot consumed
+            if (a.debug & 4) continue;
             if (c >= a.N) { atomicAdd(a.error_count, 1u); continue; }       // a listed slot must hold a column id
             if (c == r) continue;                         // identity cell is zeroed (library.cpp:485-487)
-            // score_valid needs perc >= thr or tr_perc >= thr (library.cpp:497-500).  tr_perc = tc / K_c and
-            // K_c >= min_kseq, and IEEE division is monotone in the divisor, so tc / min_kseq < thr rules the
-            // second test out without fetching K_c.
-            const float perc0 = (float) (int) ((acc >> 21) & FIELD_MASK) / f_my;
-            const float tr_ub = (float) (int) (acc >> 42) / f_min_kseq;
-            if (!(perc0 >= threshold || tr_ub >= threshold)) continue;
+            // score_valid needs perc >= thr or tr_perc >= thr (library.cpp:497-500).  Both quotients are monotone
+            // in their numerators, and tr_perc = tc / K_c <= tc / min_kseq (IEEE division is monotone in the
+            // divisor), so two integer compares against thresholds derived with the same float expressions
+            // drop a candidate without a division or a fetch of K_c.
+            if ((uint32_t) ((acc >> 21) & FIELD_MASK) < pc_min && (uint32_t) (acc >> 42) < tc_min) continue;
             float perc, tr;
             const float score = finalize_cell(acc, my_kcnt, a.kseq_len[c], threshold, perc, tr);
             if (score > 0.0f) {
@@ -290,21 +430,26 @@ __device__ __forceinline__ void st_agent(unsigned long long *p, unsigned long lo
 
 __global__ __launch_bounds__(HBM_THREADS) void k_join_hbm(JoinArgs a) {
     constexpr int JOIN_THREADS = HBM_THREADS;
-    __shared__ uint32_t s_ntouched, s_nemit, s_work;
+    __shared__ uint32_t s_ntouched, s_nemit, s_work, s_batch_end;
     __shared__ unsigned long long s_base;
     const uint32_t tid = threadIdx.x;
     unsigned long long *t_acc = a.hbm_acc + (size_t) blockIdx.x * a.N;
     uint32_t *t_first = a.hbm_u32 + (size_t) blockIdx.x * 3 * a.N;
     uint32_t *t_touched = t_first + a.N;
     uint32_t *t_emit = t_touched + a.N;
-    if (tid == 0) { s_ntouched = 0; s_nemit = 0; }
+    if (tid == 0) { s_ntouched = 0; s_nemit = 0; s_work = 0xffffffffu; s_batch_end = 0; }
     const float threshold = 1.0f / (2.0f * (float) a.k);
+    const uint32_t n_work = a.n_work_ptr ? *a.n_work_ptr : a.n_work;
     __syncthreads();
     for (;;) {
-        if (tid == 0) s_work = atomicAdd(a.work_cursor, 1u);
+        if (tid == 0) {
+            uint32_t nx = s_work + 1;
+            if (nx >= s_batch_end) { nx = atomicAdd(a.work_cursor, a.work_batch); s_batch_end = nx + a.work_batch; }
+            s_work = nx;
+        }
         __syncthreads();
         const uint32_t wi = s_work;
-        if (wi >= a.n_work) break;
+        if (wi >= n_work) break;
         const uint32_t p = a.work[wi];
         const uint32_t r = a.task_rows[p];
         const uint32_t e0 = a.seq_off[r], e1 = a.seq_off[r + 1];
@@ -456,6 +601,18 @@ __global__ __launch_bounds__(256) void k_row_desc(const uint32_t *__restrict__ t
     desc[p] = make_uint4(p, r, e0, seq_off[r + 1] - e0);
 }
 
+// descriptors of the rows a tier handed on (list of task positions, length on the device)
+__global__ __launch_bounds__(256) void k_row_desc_list(const uint32_t *__restrict__ list, const uint32_t *__restrict__ n_list,
+                                                       const uint32_t *__restrict__ task_rows, const uint32_t *__restrict__ seq_off,
+                                                       uint4 *__restrict__ desc) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= *n_list) return;
+    const uint32_t p = list[i];
+    const uint32_t r = task_rows[p];
+    const uint32_t e0 = seq_off[r];
+    desc[i] = make_uint4(p, r, e0, seq_off[r + 1] - e0);
+}
+
 struct RowCntFlag {
     const uint32_t *row_cnt;
     __device__ uint32_t operator()(uint64_t p) const { return row_cnt[p]; }
@@ -511,19 +668,46 @@ void pdl_run_score_all(pdl_ctx *c) {
     c->row_desc.alloc((size_t) n_rows * sizeof(uint4));
     hipLaunchKernelGGL(k_row_desc, dim3((n_rows + 255) / 256), dim3(256), 0, st, c->task_rows.as<uint32_t>(), c->seq_off.as<uint32_t>(),
                        n_rows, c->row_desc.as<uint4>());
-    c->overflow_rows.alloc((size_t) n_rows * 4);
+    c->overflow_rows.alloc((size_t) n_rows * 4 * 2);     // list A (tier 1 -> 2) and list B (tier 2 -> 3)
+    c->row_desc2.alloc((size_t) n_rows * sizeof(uint4));
 
     int cus = 256;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) cus = prop.multiProcessorCount; }
 
+    // ---- tiers ---------------------------------------------------------------------------------------
+    //   1  k_join_lds<FILTER>     small table + "seen twice" bitmap, several rows resident per CU
+    //   2  k_join_lds<13,1024>    128-KiB table holding every column a row touches, one row per CU
+    //   3  k_join_hbm             direct-addressed tables in HBM
+    // A tier hands the rows it cannot hold to the next one through a device-side list; the three launches are
+    // queued back to back and the counters are read once at the end.
+    // PDL_JOIN_TIER1 = 0 | 9 | 10 | 11 picks the tier-1 table (0: skip tier 1); PDL_JOIN_TABLE_BITS=9 swaps
+    // tier 2 for a tiny table so that tests can reach tier 3 with small inputs.
+    int tier1 = G <= 96 ? 9 : (G <= 320 ? 10 : 11);
+    if (const char *e = getenv("PDL_JOIN_TIER1")) { const int v = atoi(e); if (v == 0 || (v >= 9 && v <= 11)) tier1 = v; }
+    bool tiny_tier2 = false;
+    if (const char *e = getenv("PDL_JOIN_TABLE_BITS")) tiny_tier2 = atoi(e) == 9;
+    auto occupancy = [&](const void *fn, int threads) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, threads, 0) != hipSuccess || nb < 1) nb = 1;
+        return (uint32_t) nb;
+    };
+    const void *fn1 = tier1 == 9 ? (const void *) k_join_lds<9, 128, true>
+                    : tier1 == 10 ? (const void *) k_join_lds<10, 256, true> : (const void *) k_join_lds<11, 256, true>;
+    const int t1_threads = tier1 == 9 ? 128 : 256;
+    const uint32_t grid1 = tier1 ? std::min<uint32_t>(n_rows, (uint32_t) cus * occupancy(fn1, t1_threads)) : 0;
+    const uint32_t grid2 = std::min<uint32_t>(n_rows, (uint32_t) cus * (tiny_tier2 ? 4 : 1));
+    const uint32_t grid3 = (uint32_t) std::min<int>(cus, 64);
+    const size_t hbm_bytes = (size_t) grid3 * N * (sizeof(uint64_t) + 3 * sizeof(uint32_t));
+    if (c->glb_table.bytes < hbm_bytes) { c->glb_table.alloc(hbm_bytes); c->glb_clean = false; }
+    if (!c->glb_clean) {      // k_join_hbm leaves its tables zeroed: one memset per allocation
+        PDL_HIP(hipMemsetAsync(c->glb_table.p, 0, hbm_bytes, st));
+        c->glb_clean = true;
+    }
+
     // staging capacity: emitted cells are, in practice, the homologous pairs (about one per genome and row);
-    // if the guess is short the pass is repeated once with the exact size.
-    // (every workgroup reserves staging in chunks of CELL_CHUNK cells, so allow one partly used chunk per
-    // workgroup and per oversized row on top of the cell estimate)
-    int geometry = 0;
-    if (const char *e = getenv("PDL_JOIN_TABLE_BITS")) geometry = atoi(e) == 9 ? 1 : 0;
-    const uint32_t grid = std::min<uint32_t>(n_rows, (uint32_t) cus * (geometry == 1 ? 4 : 1));
-    const unsigned long long slack = 2ull * grid * CELL_CHUNK + 4ull * cus * CELL_CHUNK;
+    // if the guess is short the pass is repeated once with the exact size.  Every workgroup reserves staging in
+    // chunks of CELL_CHUNK cells: allow a partly used chunk per workgroup of every tier on top of the estimate.
+    const unsigned long long slack = 2ull * (grid1 + grid2 + grid3) * CELL_CHUNK;
     unsigned long long cap = std::max<unsigned long long>(1ull << 20, (unsigned long long) n_rows * (G + 16ull));
     cap = std::min<unsigned long long>(cap, std::max<unsigned long long>(c->P, 1ull)) + slack;
     for (int attempt = 0; attempt < 2; attempt++) {
@@ -538,47 +722,56 @@ void pdl_run_score_all(pdl_ctx *c) {
         a.post = c->post.as<uint2>(); a.ranges = c->ranges.as<uint4>(); a.seq_off = c->seq_off.as<uint32_t>();
         a.kseq_len = c->kseq_len.as<uint32_t>(); a.genome_of = c->d_gen;
         a.task_rows = c->task_rows.as<uint32_t>(); a.task_lg = c->task_lg.as<uint32_t>();
-        a.work = nullptr; a.desc = c->row_desc.as<uint4>(); a.n_work = n_rows; a.N = N; a.G = G; a.k = c->rp.k;
+        a.N = N; a.G = G; a.k = c->rp.k;
         a.min_kseq = (uint32_t) std::max<uint64_t>(c->min_kseq, 1); a.canonical = (c->flags & PDL_FLAG_CANONICAL_ORDER) ? 1u : 0u;
+        if (const char *e = getenv("PDL_JOIN_DEBUG")) a.debug = (uint32_t) atoi(e);
         a.MS = c->MS.as<float>(); a.CM = c->CM.as<float>();
         a.row_base = c->row_base.as<uint32_t>(); a.row_cnt = c->row_cnt.as<uint32_t>();
         a.st_score = c->st_score.as<float>(); a.st_perc = c->st_perc.as<float>(); a.st_tr = c->st_tr.as<float>();
         a.st_col = c->st_col.as<uint32_t>(); a.st_first = c->st_first.as<uint32_t>(); a.st_cap = cap;
+        // counters: 0 cursor tier 1 | 1 rows for tier 2 | 2 cursor tier 2 | 3 rows for tier 3 | 4-5 cell cursor | 6 errors | 7 cursor tier 3
         uint32_t *ctr32 = c->join_ctr.as<uint32_t>();
-        a.work_cursor = ctr32 + 0; a.overflow_count = ctr32 + 1; a.error_count = ctr32 + 6;
+        uint32_t *list_a = c->overflow_rows.as<uint32_t>(), *list_b = list_a + n_rows;
+        a.error_count = ctr32 + 6;
         a.cell_cursor = reinterpret_cast<unsigned long long *>(ctr32 + 4);
-        a.overflow_rows = c->overflow_rows.as<uint32_t>();
 
         ev_begin(c, EV_JOIN);
-        if (geometry == 1) hipLaunchKernelGGL((k_join_lds<9, 64>), dim3(grid), dim3(64), 0, st, a);
-        else hipLaunchKernelGGL((k_join_lds<13, 1024>), dim3(grid), dim3(1024), 0, st, a);
+        // tier 1
+        a.work = nullptr; a.desc = c->row_desc.as<uint4>(); a.n_work = n_rows; a.n_work_ptr = nullptr;
+        a.work_cursor = ctr32 + 0; a.overflow_count = ctr32 + 1; a.overflow_rows = list_a;
+        a.work_batch = std::max<uint32_t>(1, std::min<uint32_t>(8, n_rows / (std::max<uint32_t>(grid1, 1) * 8)));
+        if (tier1 == 9) hipLaunchKernelGGL((k_join_lds<9, 128, true>), dim3(grid1), dim3(128), 0, st, a);
+        else if (tier1 == 10) hipLaunchKernelGGL((k_join_lds<10, 256, true>), dim3(grid1), dim3(256), 0, st, a);
+        else if (tier1 == 11) hipLaunchKernelGGL((k_join_lds<11, 256, true>), dim3(grid1), dim3(256), 0, st, a);
+        // tier 2 over list A (or over everything when tier 1 is off)
+        if (tier1) {
+            hipLaunchKernelGGL(k_row_desc_list, dim3((n_rows + 255) / 256), dim3(256), 0, st, list_a, ctr32 + 1, c->task_rows.as<uint32_t>(),
+                               c->seq_off.as<uint32_t>(), c->row_desc2.as<uint4>());
+            a.desc = c->row_desc2.as<uint4>(); a.n_work = 0; a.n_work_ptr = ctr32 + 1;
+        }
+        a.work_cursor = ctr32 + 2; a.overflow_count = ctr32 + 3; a.overflow_rows = list_b;
+        a.work_batch = tier1 ? 1 : std::max<uint32_t>(1, std::min<uint32_t>(8, n_rows / (grid2 * 8)));
+        if (tiny_tier2) hipLaunchKernelGGL((k_join_lds<9, 64, false>), dim3(grid2), dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_join_lds<13, 1024, false>), dim3(grid2), dim3(1024), 0, st, a);
         PDL_HIP(hipGetLastError());
         ev_end(c, EV_JOIN);
-        c->tm.join_launches++;
+        // tier 3 over list B
+        a.hbm_acc = c->glb_table.as<unsigned long long>();
+        a.hbm_u32 = reinterpret_cast<uint32_t *>(a.hbm_acc + (size_t) grid3 * N);
+        a.work = list_b; a.n_work = 0; a.n_work_ptr = ctr32 + 3; a.work_cursor = ctr32 + 7; a.work_batch = 1;
+        ev_begin(c, EV_JOIN_OVF);
+        c->glb_clean = false;
+        hipLaunchKernelGGL(k_join_hbm, dim3(grid3), dim3(HBM_THREADS), 0, st, a);
+        PDL_HIP(hipGetLastError());
+        ev_end(c, EV_JOIN_OVF);
+        c->tm.join_launches += 3;
 
         uint32_t h_ctr[8];
         PDL_HIP(hipMemcpyAsync(h_ctr, c->join_ctr.p, sizeof(h_ctr), hipMemcpyDeviceToHost, st));
         PDL_HIP(hipStreamSynchronize(st));
-        const uint32_t n_ovf = h_ctr[1];
-        c->tm.overflow_rows = n_ovf;
-        c->ev[EV_JOIN_OVF].used = false;
-        if (n_ovf) {
-            // rows whose candidate set exceeded the LDS table: HBM tables, one set per workgroup
-            const uint32_t wgs = std::min<uint32_t>(n_ovf, (uint32_t) cus);
-            c->glb_table.alloc((size_t) wgs * N * (sizeof(uint64_t) + 3 * sizeof(uint32_t)));
-            PDL_HIP(hipMemsetAsync(c->glb_table.p, 0, (size_t) wgs * N * (sizeof(uint64_t) + 3 * sizeof(uint32_t)), st));
-            a.hbm_acc = c->glb_table.as<unsigned long long>();
-            a.hbm_u32 = reinterpret_cast<uint32_t *>(a.hbm_acc + (size_t) wgs * N);
-            a.work = c->overflow_rows.as<uint32_t>(); a.n_work = n_ovf;
-            a.work_cursor = ctr32 + 2;
-            ev_begin(c, EV_JOIN_OVF);
-            hipLaunchKernelGGL(k_join_hbm, dim3(wgs), dim3(HBM_THREADS), 0, st, a);
-            PDL_HIP(hipGetLastError());
-            ev_end(c, EV_JOIN_OVF);
-            c->tm.join_launches++;
-            PDL_HIP(hipMemcpyAsync(h_ctr, c->join_ctr.p, sizeof(h_ctr), hipMemcpyDeviceToHost, st));
-            PDL_HIP(hipStreamSynchronize(st));
-        }
+        c->glb_clean = true;
+        c->tm.overflow_rows = h_ctr[3];
+        c->tm.tier2_rows = tier1 ? h_ctr[1] : n_rows;
         if (h_ctr[6]) PDL_FAIL(PDL_ERR_DEVICE, "join: %u internal consistency violations", h_ctr[6]);
         unsigned long long z;                    // staging cells reserved (>= cells emitted: chunk tails are unused)
         memcpy(&z, &h_ctr[4], sizeof(z));

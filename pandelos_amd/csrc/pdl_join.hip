@@ -230,7 +230,7 @@ __global__ __launch_bounds__(T_) void k_join_lds(JoinArgs a) {
     // rs+1+l (rs = range holding the chunk's first lookup, carried in scalar registers); the starts that fall
     // inside the chunk are turned into a 64-bit boundary mask with scalar ops, and a lane's range is rs +
     // popcount(boundaries at or below the lane), its offset the distance to the last such boundary.
-    auto walk = [&](uint32_t total, auto &&fn) {
+    auto walk = [&](uint32_t total, auto &&fn4) {
         if (a.debug & 8) return;
         constexpr uint32_t NW = T / PDL_WAVE;
         const uint32_t lane = tid & (PDL_WAVE - 1), wave = tid / PDL_WAVE;
@@ -274,12 +274,12 @@ __global__ __launch_bounds__(T_) void k_join_lds(JoinArgs a) {
 #pragma unroll
             for (uint32_t u = 0; u < 4; u++)
                 if (live[u]) po[u] = (a.debug & 2) ? make_uint2(adr[u] % a.N, 1u) : a.post[adr[u]];
+            if (a.debug & 1) {
 #pragma unroll
-            for (uint32_t u = 0; u < 4; u++)
-                if (live[u] && !*(volatile uint32_t *) &s_overflow) {  // <= 1 insertion per lane after the flag: TOUCH_CAP < HT holds
-                    if (a.debug & 1) { if (po[u].x == 0xfffffff0u) s_overflow = 1; }
-                    else fn(po[u], gm[u]);
-                }
+                for (uint32_t u = 0; u < 4; u++) if (live[u] && po[u].x == 0xfffffff0u) s_overflow = 1;
+            } else {
+                fn4(po, gm, live);
+            }
         }
     };
 
@@ -311,10 +311,14 @@ __global__ __launch_bounds__(T_) void k_join_lds(JoinArgs a) {
         if constexpr (!FILTER) {
             for (uint32_t b0 = 0; b0 < nr; b0 += RB) {
                 const uint32_t total = stage(e0, b0, min(RB, nr - b0));
-                walk(total, [&](uint2 po, uint2 gm) {
-                    uint32_t seen;
-                    const uint32_t slot = find_or_insert(po.x, seen);
-                    add_to(slot, seen, po.y, gm.y, 0xffffffffu - gm.x);
+                walk(total, [&](const uint2 (&po)[4], const uint2 (&gm)[4], const bool (&live)[4]) {
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; u++) {
+                        if (!live[u] || *(volatile uint32_t *) &s_overflow) continue;   // <= 1 insertion per lane after the flag
+                        uint32_t seen;
+                        const uint32_t slot = find_or_insert(po[u].x, seen);
+                        add_to(slot, seen, po[u].y, gm[u].y, 0xffffffffu - gm[u].x);
+                    }
                 });
                 __syncthreads();
             }
@@ -325,27 +329,46 @@ __global__ __launch_bounds__(T_) void k_join_lds(JoinArgs a) {
             uint32_t total = 0;
             for (uint32_t b0 = 0; b0 < nr; b0 += RB) {       // pass 1: which columns need a slot
                 total = stage(e0, b0, min(RB, nr - b0));     // (its barriers also cover the bitmap clear)
-                walk(total, [&](uint2 po, uint2 gm) {
-                    bool ins = !filter_on || max(po.y, gm.y) >= 2;
-                    if (!ins) {
-                        const uint32_t h = (po.x * 0x9E3779B1u) >> 16;
-                        const uint32_t bit = 1u << (h & 31);
-                        ins = (atomicOr(&s_bm[h >> 5], bit) & bit) != 0;
+                walk(total, [&](const uint2 (&po)[4], const uint2 (&gm)[4], const bool (&live)[4]) {
+                    bool ins[4];
+                    uint32_t old[4], bit[4];
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; u++) {       // four bitmap atomics in flight
+                        ins[u] = live[u] && (!filter_on || max(po[u].y, gm[u].y) >= 2);
+                        const uint32_t h = (po[u].x * 0x9E3779B1u) >> 16;
+                        bit[u] = 1u << (h & 31);
+                        old[u] = (live[u] && !ins[u]) ? atomicOr(&s_bm[h >> 5], bit[u]) : 0u;
                     }
-                    if (ins) { uint32_t seen; (void) find_or_insert(po.x, seen); }
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; u++) {
+                        if ((ins[u] || (old[u] & bit[u])) && !*(volatile uint32_t *) &s_overflow) {   // <= 1 insertion per lane after the flag
+                            uint32_t seen;
+                            (void) find_or_insert(po[u].x, seen);
+                        }
+                    }
                 });
                 __syncthreads();
             }
             if (!s_overflow) {
                 for (uint32_t b0 = 0; b0 < nr; b0 += RB) {   // pass 2: add every contribution of the kept columns
                     if (nr > RB) total = stage(e0, b0, min(RB, nr - b0));   // single batch: still staged
-                    walk(total, [&](uint2 po, uint2 gm) {
-                        uint32_t slot = (po.x * 2654435761u) >> (32 - HT_BITS_);
-                        for (;;) {
-                            const uint2 kf = s_kf[slot];
-                            if (kf.x == po.x) { add_to(slot, kf.y, po.y, gm.y, 0xffffffffu - gm.x); break; }
-                            if (kf.x == EMPTY_KEY) break;    // column was seen once only
-                            slot = (slot + 1) & (HT - 1);
+                    walk(total, [&](const uint2 (&po)[4], const uint2 (&gm)[4], const bool (&live)[4]) {
+                        uint32_t slot[4];
+                        uint2 kf[4];
+#pragma unroll
+                        for (uint32_t u = 0; u < 4; u++) {   // four first probes in flight
+                            slot[u] = (po[u].x * 2654435761u) >> (32 - HT_BITS_);
+                            kf[u] = s_kf[slot[u]];
+                        }
+#pragma unroll
+                        for (uint32_t u = 0; u < 4; u++) {
+                            if (!live[u]) continue;
+                            for (;;) {
+                                if (kf[u].x == po[u].x) { add_to(slot[u], kf[u].y, po[u].y, gm[u].y, 0xffffffffu - gm[u].x); break; }
+                                if (kf[u].x == EMPTY_KEY) break;     // column was seen once only
+                                slot[u] = (slot[u] + 1) & (HT - 1);
+                                kf[u] = s_kf[slot[u]];
+                            }
                         }
                     });
                     __syncthreads();
@@ -682,7 +705,7 @@ void pdl_run_score_all(pdl_ctx *c) {
     // queued back to back and the counters are read once at the end.
     // PDL_JOIN_TIER1 = 0 | 9 | 10 | 11 picks the tier-1 table (0: skip tier 1); PDL_JOIN_TABLE_BITS=9 swaps
     // tier 2 for a tiny table so that tests can reach tier 3 with small inputs.
-    int tier1 = G <= 96 ? 9 : (G <= 320 ? 10 : 11);
+    int tier1 = G <= 320 ? 10 : 11;     // keys per row ~ homologs (about one per genome) + repeated/colliding noise
     if (const char *e = getenv("PDL_JOIN_TIER1")) { const int v = atoi(e); if (v == 0 || (v >= 9 && v <= 11)) tier1 = v; }
     bool tiny_tier2 = false;
     if (const char *e = getenv("PDL_JOIN_TABLE_BITS")) tiny_tier2 = atoi(e) == 9;

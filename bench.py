@@ -14,9 +14,9 @@ value = N*(N-1) ordered gene pairs / seconds per step  (the refe
 row gene against all N columns).
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the genome tasks are sharded over the
-ranks (LPT on the reference's per-genome cost); the workload is the same set, so scaling is
-"strong".  Round-1 status: every rank builds the whole dictionary itself (no data-path collective
-yet).
+ranks (LPT on residues per genome, fixed before the dictionary build); the workload is the same set,
+so scaling is "strong".  Round-1 status: every rank builds the dictionary postings itself, range lists
+and scoring are per shard; collectives carry only scalar totals.
 
 Extra objects on the JSON line:
   roofline     dominant kernel = K-join; achieved = algorithmic bytes of the join launch
@@ -42,18 +42,6 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-
-
-def lpt_shards(costs, n):
-    """Longest-processing-time assignment of genomes to n ranks by the reference's per-genome cost."""
-    order = np.argsort(-np.asarray(costs, dtype=np.float64), kind="stable")
-    loads = [0.0] * n
-    shards = [[] for _ in range(n)]
-    for g in order:
-        r = int(np.argmin(loads))
-        shards[r].append(int(g))
-        loads[r] += float(costs[g])
-    return [sorted(s) for s in shards]
 
 
 def cpu_baseline(gs, k, pairs, max_threads):
@@ -137,23 +125,19 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     torch.cuda.synchronize()
 
-    state = {"shard": None}
+    from pandelos_amd import distributed as D
 
-    ctx = {"nat": None}
+    # one context per rank for the whole run: every step redoes all the work, only allocations are reused.
+    # N > 1: genomes are dealt to ranks once (LPT on residues per genome); the shard is in force before the
+    # dictionary build, so a rank builds range lists for, and scores, only its own genes.
+    nat = PangeneNative.open(stream=stream)
+    if n_gpus > 1:
+        shard = D.shard_for_rank(gs.offsets, gs.genome_of, n_gpus, rank)
+        D.gather_genome_owner(shard, n_genomes, device=dev)      # the shards must partition the genomes
+        nat.set_genome_shard(shard)
 
     def one_step():
-        # one context for the whole run: every step redoes all the work, only allocations are reused
-        if ctx["nat"] is None:
-            ctx["nat"] = PangeneNative.from_device(k, t_res.data_ptr(), t_off.data_ptr(), t_gen.data_ptr(), n_genes,
-                                                   len(gs.residues), stream=stream)
-        else:
-            ctx["nat"].preprocess_device(k, t_res.data_ptr(), t_off.data_ptr(), t_gen.data_ptr(), n_genes, len(gs.residues))
-        nat = ctx["nat"]
-        if n_gpus > 1:
-            if state["shard"] is None:
-                costs = [nat.genome_cost(g) for g in range(n_genomes)]
-                state["shard"] = lpt_shards(costs, n_gpus)[rank]
-            nat.set_genome_shard(state["shard"])
+        nat.preprocess_device(k, t_res.data_ptr(), t_off.data_ptr(), t_gen.data_ptr(), n_genes, len(gs.residues))
         nat.score_all()
         return nat
 
@@ -162,24 +146,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    nat = None
     for _ in range(args.warmup):
-        nat = one_step()
+        one_step()
     sync()
     t0 = time.perf_counter()
     join_ms, pre_ms, score_ms = [], [], []
     for _ in range(args.steps):
-        nat = one_step()
+        one_step()
         tm = nat.timings()
         join_ms.append(tm["join_ms"] + tm["join_overflow_ms"])
         pre_ms.append(tm["preprocess_total_ms"])
         score_ms.append(tm["score_total_ms"])
     sync()
     elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = D.all_reduce_max(elapsed, device=dev)
     sec_per_step = elapsed / max(args.steps, 1)
 
     cost = nat.cost
@@ -189,13 +169,9 @@ def main():
     join_bytes = 8.0 * p_l + 20.0 * z_l + 8.0 * rows_l * n_genomes
     join_s = (sum(join_ms) / len(join_ms)) / 1e3 if join_ms else 0.0
     achieved = join_bytes / join_s / 1e9 if join_s > 0 else 0.0
-    z_total = float(z_l)
-    if distributed:
-        t = torch.tensor([z_total], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        z_total = float(t.item())
+    z_total, p_total = D.all_reduce_sum([float(z_l), float(cost.total_cost)], device=dev)
     bytes_alg_total = (cost.residues + 16.0 * cost.kmer_occurrences + 16.0 * cost.dictionary_records +
-                       8.0 * cost.total_cost + 20.0 * z_total + 8.0 * n_genes * n_genomes)
+                       8.0 * p_total + 20.0 * z_total + 8.0 * n_genes * n_genomes)
 
     out = {
         "metric": "scored gene-pairs/sec (whole node)",
@@ -210,15 +186,16 @@ def main():
         "data": data_kind,
         "config": {"workload": workload, "genes": n_genes, "genomes": n_genomes, "residues": int(cost.residues),
                    "k": int(k), "kmer_occurrences": int(cost.kmer_occurrences),
-                   "dictionary_records": int(cost.dictionary_records), "lookups": int(cost.total_cost),
-                   "emitted_cells": int(z_total), "sharding": f"genome tasks over {n_gpus} GPU(s), dictionary replicated"},
+                   "dictionary_records": int(cost.dictionary_records), "lookups": int(p_total),
+                   "emitted_cells": int(z_total), "sharding": f"genome tasks over {n_gpus} GPU(s) (LPT on residues); postings built on every rank, "
+                               "range lists and scoring per shard"},
         "achieved_hbm_GBps_whole_path": bytes_alg_total / sec_per_step / 1e9,
-        "lookups_per_s": cost.total_cost / sec_per_step,
+        "lookups_per_s": p_total / sec_per_step,
         "stage_ms": {"preprocess": sum(pre_ms) / len(pre_ms), "score": sum(score_ms) / len(score_ms),
                      "hist": tm["hist_ms"], "rank": tm["rank_ms"], "sort_rank": tm["sort_rank_ms"], "dict": tm["dict_ms"],
                      "sort_seq": tm["sort_seq_ms"], "ranges": tm["ranges_ms"], "join": tm["join_ms"],
                      "join_overflow": tm["join_overflow_ms"], "order": tm["order_ms"],
-                     "overflow_rows": tm["overflow_rows"]},
+                     "tier2_rows": tm["tier2_rows"], "overflow_rows": tm["overflow_rows"]},
         "roofline": {"bound": "hbm", "kernel": "k_join_lds (+k_join_hbm)", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                      "bytes_per_launch": join_bytes, "launch_ms": join_s * 1e3},

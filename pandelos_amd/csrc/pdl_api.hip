@@ -92,12 +92,18 @@ static void build_genome_layout(pdl_ctx *c) {
 static int preprocess_common(pdl_ctx *c, uint32_t n, uint64_t n_res, int k, int only_complexity, pdl_cost *out_cost) {
     PDL_GUARD_BEGIN
     PDL_HIP(hipSetDevice(c->device));
-    c->preprocessed = false; c->scored = false; c->shard_set = false; c->shard.clear();
+    c->preprocessed = false; c->scored = false;      // the genome shard, if one was set, stays in force
     c->N = n; c->R = n_res;
     c->U = c->Ushared = c->NG = c->P = c->M = 0;
     if (k <= 0) PDL_FAIL(PDL_ERR_KVALUE, "K value must be greater than 0.");
     if (n == 0) PDL_FAIL(PDL_ERR_EMPTY, "empty dataset");
     build_genome_layout(c);
+    c->dict_shard.clear();
+    if (c->shard_set) {
+        for (uint32_t g : c->shard)
+            if (g >= c->G) PDL_FAIL(PDL_ERR_ARGUMENT, "genome shard: id %u out of range (%u genomes)", g, c->G);
+        c->dict_shard = c->shard;            // posting-range lists are built for these genomes' genes only
+    }
     pdl_run_preprocess(c, k, only_complexity != 0);
     c->preprocessed = true;
     fill_cost(c, out_cost);
@@ -166,14 +172,22 @@ int pdl_sequence_costs(const pdl_ctx *cc, uint64_t *out_cost, uint32_t *out_kseq
 int pdl_set_genome_shard(pdl_ctx *c, const uint32_t *genomes, uint32_t count) {
     if (!c || (!genomes && count)) return PDL_ERR_ARGUMENT;
     std::lock_guard<std::mutex> lk(c->mu);
-    if (!c->preprocessed) { c->err = "pdl_set_genome_shard before pdl_preprocess"; return PDL_ERR_STATE; }
     std::vector<uint32_t> s(genomes, genomes + count);
     std::sort(s.begin(), s.end());
     for (size_t i = 0; i < s.size(); i++) {
-        if (s[i] >= c->G || (i && s[i] == s[i - 1])) { c->err = "genome shard: id out of range or repeated"; return PDL_ERR_ARGUMENT; }
+        if ((c->preprocessed && s[i] >= c->G) || (i && s[i] == s[i - 1])) { c->err = "genome shard: id out of range or repeated"; return PDL_ERR_ARGUMENT; }
+    }
+    if (c->preprocessed && !c->dict_shard.empty()) {
+        // the dictionary on the device only has range lists for the genes of dict_shard
+        for (uint32_t g : s)
+            if (!std::binary_search(c->dict_shard.begin(), c->dict_shard.end(), g)) {
+                c->err = "genome shard: not a subset of the shard the dictionary was built for; run pdl_preprocess again";
+                return PDL_ERR_STATE;
+            }
+        if (count == 0) { c->err = "genome shard: the dictionary was built for a shard; run pdl_preprocess again to widen it"; return PDL_ERR_STATE; }
     }
     c->shard = std::move(s);
-    c->shard_set = true;
+    c->shard_set = count != 0;
     c->scored = false;
     return PDL_OK;
 }

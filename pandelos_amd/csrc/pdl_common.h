@@ -121,6 +121,8 @@ struct pdl_ctx {
     std::vector<uint32_t> h_genome_rows;      // gene ids grouped by genome, ascending inside a genome
     std::vector<uint32_t> shard;              // genomes scored by this context (ascending)
     bool shard_set = false;
+    std::vector<uint32_t> dict_shard;         // genomes whose genes have range lists on the device (empty = all)
+    DevBuf seq_in_shard;                      // u8 [N] gene belongs to dict_shard
 
     // scoring results (device)
     bool scored = false;

@@ -282,7 +282,12 @@ __global__ __launch_bounds__(256) void k_record_costs(const uint2 *__restrict__ 
 // scattered counters run at the memory side on this chip.)
 struct SharedFlag {
     const uint32_t *gid; const uint32_t *goff;
-    __device__ uint32_t operator()(uint64_t u) const { uint32_t g = gid[u]; return (goff[g + 1] - goff[g]) >= 2 ? 1u : 0u; }
+    const uint2 *post; const uint8_t *in_shard;      // in_shard == nullptr: every gene gets a range list
+    __device__ uint32_t operator()(uint64_t u) const {
+        uint32_t g = gid[u];
+        if ((goff[g + 1] - goff[g]) < 2) return 0u;
+        return in_shard ? (uint32_t) in_shard[post[u].x] : 1u;
+    }
 };
 struct SharedScatter {
     const uint2 *post; const uint32_t *gid; const uint32_t *goff;
@@ -439,7 +444,18 @@ static void dictionary_pipeline(pdl_ctx *c, bool only_complexity) {
         uint32_t *v2a = reinterpret_cast<uint32_t *>(tuples + U);
         uint32_t *k2b = v2a + U;
         uint32_t *v2b = k2b + U;
-        scan_and_apply(c, U, SharedFlag{c->gid.as<uint32_t>(), c->goff.as<uint32_t>()},
+        const uint8_t *in_shard = nullptr;
+        if (!c->dict_shard.empty()) {       // multi-GPU: only the genes this context scores need range lists
+            std::vector<uint8_t> h((size_t) c->N, 0);
+            std::vector<uint8_t> gsel((size_t) c->G, 0);
+            for (uint32_t g : c->dict_shard) gsel[g] = 1;
+            for (uint32_t i = 0; i < c->N; i++) h[i] = gsel[c->h_genome_of[i]];
+            c->seq_in_shard.alloc(c->N);
+            PDL_HIP(hipMemcpyAsync(c->seq_in_shard.p, h.data(), c->N, hipMemcpyHostToDevice, st));
+            PDL_HIP(hipStreamSynchronize(st));
+            in_shard = c->seq_in_shard.as<uint8_t>();
+        }
+        scan_and_apply(c, U, SharedFlag{c->gid.as<uint32_t>(), c->goff.as<uint32_t>(), c->post.as<uint2>(), in_shard},
                        SharedScatter{c->post.as<uint2>(), c->gid.as<uint32_t>(), c->goff.as<uint32_t>(), k2a, v2a, tuples}, d_scal + 2);
         uint64_t Us = 0;
         PDL_HIP(hipMemcpyAsync(&Us, d_scal + 2, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
@@ -475,7 +491,7 @@ static void dictionary_pipeline(pdl_ctx *c, bool only_complexity) {
     PDL_HIP(hipStreamSynchronize(st));
     c->Ushared = tail[2];
     // every record outside the shared groups is a group of its own: shared groups = all groups - singletons
-    c->NG = tail[1] - (c->U - c->Ushared);
+    c->NG = c->dict_shard.empty() ? tail[1] - (c->U - c->Ushared) : 0;   // (not counted when only a shard's lists are built)
     c->sum_kseq = tail[4];
     c->max_kseq = tail[7];
     c->min_kseq = tail[8] == ~0ull ? 1 : tail[8];

@@ -56,6 +56,14 @@ class PangeneNative:
                                              int(k), int(only_complexity), C.byref(self.cost))
         self._check(rc)
 
+    @classmethod
+    def open(cls, device=-1, stream=None, flags=0) -> "PangeneNative":
+        """A context without a dictionary yet (set a genome shard, then preprocess)."""
+        self = cls.__new__(cls)
+        self._open(device, stream, flags)
+        self.cost = _lib.PdlCost()
+        return self
+
     @staticmethod
     def print_complexity(k: int, data: PangeneIData) -> "PangeneNative":
         """PangeneNative.printComplexity (PangeneNative.java:10-12): cost model only."""
@@ -77,6 +85,10 @@ class PangeneNative:
 
     def _init(self, k, residues, offsets, genome_of, only_complexity, device, stream, flags):
         self._open(device, stream, flags)
+        self.preprocess(k, residues, offsets, genome_of, only_complexity)
+
+    def preprocess(self, k, residues, offsets, genome_of, only_complexity=False):
+        """(Re)run preprocessSequences on this context from host arrays."""
         res = np.ascontiguousarray(residues, dtype=np.uint8)
         off = np.ascontiguousarray(offsets, dtype=np.uint64)
         gen = np.ascontiguousarray(genome_of, dtype=np.uint32)

@@ -160,3 +160,25 @@ def test_hbm_table_path_matches_oracle_on_dense_set(monkeypatch):
     for g in range(ora.genomes):
         H.assert_scores_equal(nat.generate_scores_part(g).as_dict(), ora.scores(g), f"genome {g}")
     assert nat.timings()["overflow_rows"] > 1000
+
+
+def test_shard_set_before_preprocess_builds_only_its_rows():
+    """Multi-GPU path: the shard is known before the dictionary build, so range lists / costs exist for its genes only;
+    two disjoint shards together reproduce the unsharded result and total cost."""
+    from pandelos_amd.pangene_native import PangeneNative
+    from pandelos_amd import _lib
+    res, off, gen, k, fx = H.load_small("synth_5x60x80_k3")
+    total = 0
+    for shard in ([0, 2, 4], [1, 3]):
+        nat = PangeneNative.open()
+        nat.set_genome_shard(shard)
+        nat.preprocess(k, res, off, gen)
+        total += nat.cost.total_cost
+        for g in shard:
+            assert nat.genome_cost(g) == int(fx["genome_cost"][g])
+            got = nat.generate_scores_part(g).as_dict()
+            for f in H.FIELDS:
+                assert np.array_equal(H.raw(got[f]), fx[f"g{g}_{f}"]), (g, f)
+        with pytest.raises(_lib.PdlError):
+            nat.set_genome_shard([0, 1, 2, 3, 4])       # wider than what the dictionary was built for
+    assert total == int(fx["total_cost"])

@@ -6,8 +6,8 @@
 //
 //   pass 1  k_scan_tile_sums   tile sums of flag(i)                 -> tile_sums[t]
 //   pass 2  k_scan_tile_scan   exclusive scan of the tile sums (one workgroup), total -> *d_total
-//   pass 3  k_scan_apply       per tile: flags staged in LDS, workgroup exclusive scan,
-//                              apply(i, flag, exclusive_prefix)
+//   pass 3  k_scan_apply       per tile: flags staged in LDS, workgroup exclusive scan, per-item prefixes
+//                              back through LDS so that apply(i, flag, exclusive_prefix) runs lane-coalesced
 //
 // FlagF :  __device__ uint32_t operator()(uint64_t i) const      (any small count, not only 0/1)
 // ApplyF:  __device__ void operator()(uint64_t i, uint32_t flag, uint32_t exclusive_prefix) const
@@ -88,6 +88,7 @@ static __global__ __launch_bounds__(1024) void k_scan_tile_scan(uint32_t *tile_s
 template <class FlagF, class ApplyF>
 __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(FlagF flag, ApplyF apply, uint64_t n, const uint32_t *tile_sums) {
     __shared__ uint32_t s_flags[SCAN_TILE];
+    __shared__ uint32_t s_pref[SCAN_TILE];
     __shared__ uint32_t s_wave[17];
     const uint64_t base = (uint64_t) blockIdx.x * SCAN_TILE;
 #pragma unroll
@@ -104,10 +105,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(FlagF flag, ApplyF 
     uint32_t total;
     uint32_t prefix = block_exclusive_scan_u32(sum, s_wave, total) + tile_sums[blockIdx.x];
 #pragma unroll
-    for (int j = 0; j < SCAN_ITEMS; j++) {
-        uint64_t i = base + (uint64_t) threadIdx.x * SCAN_ITEMS + j;
-        if (i < n) apply(i, f[j], prefix);
-        prefix += f[j];
+    for (int j = 0; j < SCAN_ITEMS; j++) { s_pref[threadIdx.x * SCAN_ITEMS + j] = prefix; prefix += f[j]; }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; j++) {           // apply in the same coalesced order the flags were read in
+        uint32_t li = j * SCAN_THREADS + threadIdx.x;
+        uint64_t i = base + li;
+        if (i < n) apply(i, s_flags[li], s_pref[li]);
     }
 }
 

@@ -123,11 +123,13 @@ PDL_API int pdl_genome_cost(const pdl_ctx *, uint32_t genome, uint64_t *out_cost
 PDL_API int pdl_sequence_costs(const pdl_ctx *, uint64_t *out_total_visited /* [N] */, uint32_t *out_kseq_lengths /* [N], may be NULL */);
 
 /* Restrict the genomes this context scores (multi-GPU sharding: one context per GPU, each with the
- * full dictionary postings and a disjoint genome list).  Set BEFORE pdl_preprocess, the posting-range
- * lists, per-gene costs and pdl_cost.total_cost are built for the shard's genes only (the part of the
- * dictionary build that is proportional to the rows scored); set after it, only the scoring is
- * restricted (and the shard must lie inside the one the dictionary was built for).  count == 0 clears
- * the shard.  The shard stays in force across pdl_preprocess calls. */
+ * full dictionary postings and a disjoint genome list).  Must be set BEFORE pdl_preprocess: the
+ * posting-range lists, per-gene costs and pdl_cost.total_cost are then built for the shard's genes only
+ * (the part of the dictionary build that is proportional to the rows scored).  Without a shard the
+ * range lists hold only the genes above each row and every cell is produced once for both of its rows, so
+ * a dictionary built for all genomes cannot score a subset (PDL_ERR_STATE); a dictionary built for a shard
+ * can be narrowed further.  count == 0 clears the shard.  The shard stays in force across
+ * pdl_preprocess calls. */
 PDL_API int pdl_set_genome_shard(pdl_ctx *, const uint32_t *genomes, uint32_t count);
 
 /* computeScores for every genome of the shard in one device pass (library.cpp:409-527 for each

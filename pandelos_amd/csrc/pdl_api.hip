@@ -177,6 +177,12 @@ int pdl_set_genome_shard(pdl_ctx *c, const uint32_t *genomes, uint32_t count) {
     for (size_t i = 0; i < s.size(); i++) {
         if ((c->preprocessed && s[i] >= c->G) || (i && s[i] == s[i - 1])) { c->err = "genome shard: id out of range or repeated"; return PDL_ERR_ARGUMENT; }
     }
+    if (c->preprocessed && c->upper_only && count != 0 && s.size() != c->G) {
+        // without a shard the ranges hold only the genes above each row and every cell is produced once for both
+        // rows; scoring a subset needs the full ranges of a shard-aware build
+        c->err = "genome shard: set it before pdl_preprocess (the dictionary on the device was built for all genomes)";
+        return PDL_ERR_STATE;
+    }
     if (c->preprocessed && !c->dict_shard.empty()) {
         // the dictionary on the device only has range lists for the genes of dict_shard
         for (uint32_t g : s)

@@ -110,6 +110,7 @@ struct pdl_ctx {
     DevBuf goff;          // u32 [NG+1] first record of each group
     DevBuf ranges;        // uint4 [U'] {group start, group length, own count, 0}, gene major
     DevBuf seq_off;       // u32 [N+1] range list of each gene
+    bool upper_only = false;  // ranges hold only the columns above the row: the join mirrors every cell
     DevBuf scan_tmp;      // block sums of the scans
     DevBuf scratch;       // transient buffers of the range build
     DevBuf scalars;       // u64 [16] device-side totals
@@ -145,6 +146,8 @@ struct pdl_ctx {
     DevBuf glb_table;     // HBM tables of the overflow pass
     bool glb_clean = false;   // all-zero (k_join_hbm leaves them that way)
     DevBuf row_desc2;     // descriptors of the rows handed from tier 1 to tier 2
+    DevBuf st_src, taskpos_of, mirror_cnt, mirror_ref;   // mirror mode (see pdl_join.hip)
+    std::vector<uint32_t> h_task_rows_host;
 
     pdl_timings tm{};
     EventPair ev[12];

@@ -8,12 +8,13 @@
 //   K-sort    pdl_sort_pairs      stable LSD radix sort by rank              library.cpp:172-187,270-278
 //   K-rle     RecHead/RecScatter, k_build_records   dedup -> (rank,gene,count)   library.cpp:280-287
 //   K-groups  GroupHead scan, k_group_offsets, k_record_costs (+ the last-record fold)  library.cpp:297-335
-//   K-ranges  k_range_slots, seq_off scan, k_place_ranges, k_row_costs          library.cpp:318-327
+//   K-ranges  SharedScatter compaction, sort by gene, k_gather_ranges, k_seq_offsets, k_row_costs   library.cpp:312-327
 //   K-cost    k_genome_cost       per-genome and total lookups               library.cpp:337-350,535-538
 //
 // HBM layout after this stage (what the join reads):
 //   post   uint2[U]   {gene, count}       rank-group major, ascending gene inside a group
-//   ranges uint4[U']  {group start, group length, own count, 0}   gene major (U' = records in groups >= 2)
+//   ranges uint4[U']  {first posting, postings, own count, group size}   gene major (U' = records in groups >= 2);
+//                     without a shard a gene's range holds only the postings after its own record (genes above it)
 //   seq_off u32[N+1]  range list of each gene;   kseq_len u32[N];   cost u64[N]
 #include "pdl_common.h"
 #include "pdl_scan.h"
@@ -248,6 +249,43 @@ struct GroupScatter {
 };
 __global__ void k_close_offsets(uint32_t *goff, const uint64_t *d_ng, uint32_t u_count) { goff[*d_ng] = u_count; }
 
+// The reference re-sorts every shared group by gene (library.cpp:312-315).  After the stable sort all groups
+// already are in gene order except the last one when the globally last record was folded into it (:300-306):
+// move that record to its place (insertion into a sorted run).  One workgroup; recpos moves along so that
+// (rank via recpos, gene, count) stay one record.  The join's "columns above the row" trick relies on this order.
+__global__ __launch_bounds__(1024) void k_fold_last_record(uint2 *__restrict__ post, uint32_t *__restrict__ recpos,
+                                                           const uint32_t *__restrict__ goff, const uint64_t *d_ng, uint32_t u_count) {
+    __shared__ uint32_t s_p;
+    if (u_count < 2) return;
+    const uint32_t gs = goff[*d_ng - 1];
+    const uint32_t lastp = u_count - 1;
+    const uint2 last = post[lastp];
+    const uint32_t last_rp = recpos[lastp];
+    if (threadIdx.x == 0) {
+        uint32_t lo = gs, hi = lastp;                    // first index in [gs, lastp) whose gene is above the last record's
+        while (lo < hi) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if (post[mid].x <= last.x) lo = mid + 1; else hi = mid;
+        }
+        s_p = lo;
+    }
+    __syncthreads();
+    const uint32_t p = s_p;
+    if (p == lastp) return;                              // already in place (uniform)
+    for (uint32_t hi = lastp; hi > p; hi = hi > 1024 ? hi - 1024 : 0) {
+        const bool live = hi >= 1 + threadIdx.x && hi - 1 - threadIdx.x >= p;
+        const uint32_t i = hi - 1 - threadIdx.x;
+        uint2 v = make_uint2(0, 0);
+        uint32_t rp = 0;
+        if (live) { v = post[i]; rp = recpos[i]; }
+        __syncthreads();
+        if (live) { post[i + 1] = v; recpos[i + 1] = rp; }
+        __syncthreads();
+        if (hi <= 1024) break;
+    }
+    if (threadIdx.x == 0) { post[p] = last; recpos[p] = last_rp; }
+}
+
 // total_visited (library.cpp:327) straight from the records: every record of a group with >= 2 records
 // adds the group size to its gene.  Only used in complexity-only mode (no range lists to sum over).
 __global__ __launch_bounds__(256) void k_record_costs(const uint2 *__restrict__ post, const uint32_t *__restrict__ gid,
@@ -283,22 +321,32 @@ __global__ __launch_bounds__(256) void k_record_costs(const uint2 *__restrict__ 
 struct SharedFlag {
     const uint32_t *gid; const uint32_t *goff;
     const uint2 *post; const uint8_t *in_shard;      // in_shard == nullptr: every gene gets a range list
+    uint32_t upper_only;                             // 1: the last member of a group has nothing above it: no range
     __device__ uint32_t operator()(uint64_t u) const {
-        uint32_t g = gid[u];
-        if ((goff[g + 1] - goff[g]) < 2) return 0u;
+        const uint32_t g = gid[u];
+        const uint32_t ge = goff[g + 1];
+        if ((ge - goff[g]) < 2) return 0u;
+        if (upper_only) return (uint32_t) u + 1 < ge ? 1u : 0u;
         return in_shard ? (uint32_t) in_shard[post[u].x] : 1u;
     }
 };
 struct SharedScatter {
     const uint2 *post; const uint32_t *gid; const uint32_t *goff;
     uint32_t *key2; uint32_t *val2; uint4 *tuples;
+    uint32_t upper_only;       // 1: a gene's range covers only the postings AFTER its own record (genes above it)
+    unsigned long long *cost;  // upper_only: the group size of a group's last member is added here (it has no range)
     __device__ void operator()(uint64_t u, uint32_t f, uint32_t prefix) const {
-        if (!f) return;
         const uint32_t g = gid[u];
-        const uint32_t gs = goff[g];
+        const uint32_t gs = goff[g], ge = goff[g + 1];
+        if (!f) {
+            if (upper_only && ge - gs >= 2 && (uint32_t) u + 1 == ge) atomicAdd(&cost[post[u].x], (unsigned long long) (ge - gs));
+            return;
+        }
         const uint2 po = post[u];
-        key2[prefix] = po.x; val2[prefix] = prefix;
-        tuples[prefix] = make_uint4(gs, goff[g + 1] - gs, po.y, 0u);
+        const uint32_t start = upper_only ? (uint32_t) u + 1 : gs;
+        key2[prefix] = po.x;
+        val2[prefix] = prefix;
+        tuples[prefix] = make_uint4(start, ge - start, po.y, ge - gs);      // {first posting, postings, own count, group size}
     }
 };
 __global__ __launch_bounds__(256) void k_gather_ranges(const uint32_t *__restrict__ idx_sorted, const uint4 *__restrict__ tuples,
@@ -306,15 +354,15 @@ __global__ __launch_bounds__(256) void k_gather_ranges(const uint32_t *__restric
     const uint32_t e = blockIdx.x * 256 + threadIdx.x;
     if (e < n) ranges[e] = tuples[idx_sorted[e]];
 }
-// seq_off[s] = first range of gene s in the gene-sorted list (lower bound), seq_off[N] = U'
-__global__ __launch_bounds__(256) void k_seq_offsets(const uint32_t *__restrict__ seq_sorted, uint32_t n, uint32_t n_seq,
+// seq_off[s] = first range of gene s in the gene-sorted list (lower bound), seq_off[N] = number of ranges
+__global__ __launch_bounds__(256) void k_seq_offsets(const uint32_t *__restrict__ key_sorted, uint32_t n, uint32_t n_seq,
                                                      uint32_t *__restrict__ seq_off) {
     const uint32_t s = blockIdx.x * 256 + threadIdx.x;
     if (s > n_seq) return;
     uint32_t lo = 0, hi = n;
     while (lo < hi) {
         uint32_t mid = lo + ((hi - lo) >> 1);
-        if (seq_sorted[mid] < s) lo = mid + 1; else hi = mid;
+        if (key_sorted[mid] < s) lo = mid + 1; else hi = mid;
     }
     seq_off[s] = lo;
 }
@@ -326,10 +374,10 @@ __global__ __launch_bounds__(256) void k_row_costs(const uint4 *__restrict__ ran
     if (s >= n_seq) return;
     const uint32_t lane = threadIdx.x & (PDL_WAVE - 1);
     unsigned long long sum = 0;
-    for (uint32_t e = seq_off[s] + lane; e < seq_off[s + 1]; e += PDL_WAVE) sum += ranges[e].y;
+    for (uint32_t e = seq_off[s] + lane; e < seq_off[s + 1]; e += PDL_WAVE) sum += ranges[e].w;
 #pragma unroll
     for (int d = PDL_WAVE / 2; d > 0; d >>= 1) sum += __shfl_down(sum, d, PDL_WAVE);
-    if (lane == 0) cost[s] = sum;
+    if (lane == 0) cost[s] += sum;      // on top of what the range-less last members of groups added
 }
 
 // K-cost: per-genome cost (library.cpp:535-538); the total is their sum (library.cpp:337-349).
@@ -424,6 +472,8 @@ static void dictionary_pipeline(pdl_ctx *c, bool only_complexity) {
     // K-groups
     scan_and_apply(c, U, GroupHeadFlag{ghead}, GroupScatter{c->gid.as<uint32_t>(), c->goff.as<uint32_t>()}, d_scal + 1);
     hipLaunchKernelGGL(k_close_offsets, dim3(1), dim3(1), 0, st, c->goff.as<uint32_t>(), d_scal + 1, Uu);
+    hipLaunchKernelGGL(k_fold_last_record, dim3(1), dim3(1024), 0, st, c->post.as<uint2>(), c->recpos.as<uint32_t>(), c->goff.as<uint32_t>(),
+                       d_scal + 1, Uu);
     PDL_HIP(hipGetLastError());
     ev_end(c, EV_DICT);
 
@@ -455,8 +505,12 @@ static void dictionary_pipeline(pdl_ctx *c, bool only_complexity) {
             PDL_HIP(hipStreamSynchronize(st));
             in_shard = c->seq_in_shard.as<uint8_t>();
         }
-        scan_and_apply(c, U, SharedFlag{c->gid.as<uint32_t>(), c->goff.as<uint32_t>(), c->post.as<uint2>(), in_shard},
-                       SharedScatter{c->post.as<uint2>(), c->gid.as<uint32_t>(), c->goff.as<uint32_t>(), k2a, v2a, tuples}, d_scal + 2);
+        const uint32_t upper_only = c->dict_shard.empty() ? 1u : 0u;
+        PDL_HIP(hipMemsetAsync(c->cost.p, 0, (size_t) c->N * sizeof(uint64_t), st));
+        scan_and_apply(c, U, SharedFlag{c->gid.as<uint32_t>(), c->goff.as<uint32_t>(), c->post.as<uint2>(), in_shard, upper_only},
+                       SharedScatter{c->post.as<uint2>(), c->gid.as<uint32_t>(), c->goff.as<uint32_t>(), k2a, v2a, tuples,
+                                     upper_only, c->cost.as<unsigned long long>()}, d_scal + 2);
+        c->upper_only = upper_only != 0;
         uint64_t Us = 0;
         PDL_HIP(hipMemcpyAsync(&Us, d_scal + 2, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
         PDL_HIP(hipStreamSynchronize(st));

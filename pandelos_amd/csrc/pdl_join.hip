@@ -55,6 +55,10 @@ struct JoinArgs {
     uint32_t *row_base, *row_cnt;  // [n_task_rows]
     float *st_score, *st_perc, *st_tr;
     uint32_t *st_col, *st_first;
+    uint32_t *st_src;              // mirror mode: gene id of the row that produced the staged cell
+    uint32_t mirror;               // 1: ranges hold only columns above the row; every cell (r,c) also stands for (c,r)
+    const uint32_t *taskpos_of;    // mirror mode: task position of every gene
+    uint32_t *mirror_cnt;          // mirror mode: mirrored cells per task position
     unsigned long long st_cap;
     uint32_t *work_cursor;         // persistent-workgroup row dispenser (one atomic hands out `work_batch` items:
                                    // a single device-scope word serves only ~90 dequeues/us)
@@ -141,7 +145,8 @@ __global__ __launch_bounds__(T_) void k_join_lds(JoinArgs a) {
     __shared__ uint2 s_kf[HT];                       // {column id, 0xffffffff - smallest group start that touched it}
     __shared__ uint32_t s_bm[FILTER ? BM_WORDS : 1];
     __shared__ uint16_t s_touched[TOUCH_CAP];
-    __shared__ uint2 s_gm[RB + 1];                   // staged ranges: {group start, own count}
+    __shared__ uint2 s_gm[RB + 1];                   // staged ranges: {first posting, own count}
+    __shared__ uint32_t s_gsv[RB + 1];               // and the start of their group (identifies the group: emission order)
     __shared__ uint32_t s_cum[RB + 66];               // exclusive prefix of their lengths, 0xffffffff beyond the batch
     __shared__ uint32_t s_wave[17];
     __shared__ uint2 s_wstart[T_ / PDL_WAVE];          // per wave: {range holding the first lookup of its segment, that range's start}
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(T_) void k_join_lds(JoinArgs a) {
     for (uint32_t i = tid; i < HT; i += T) { s_kf[i] = make_uint2(EMPTY_KEY, 0u); s_acc[i] = 0; }
     for (uint32_t i = RB + tid; i < RB + 66; i += T) s_cum[i] = 0xffffffffu;
     if (tid == 0) {
-        s_gm[RB] = make_uint2(0u, 0u);
+        s_gm[RB] = make_uint2(0u, 0u); s_gsv[RB] = 0u;
         s_ntouched = 0; s_nemit = 0; s_overflow = 0; s_chunk_next = 0; s_chunk_end = 0;
         const uint32_t w0 = atomicAdd(a.work_cursor, a.work_batch);
         s_next = w0; s_batch_end = w0 + a.work_batch;
@@ -198,7 +203,7 @@ __global__ __launch_bounds__(T_) void k_join_lds(JoinArgs a) {
             len[j] = 0;
             if (i < nb) {
                 const uint4 rg = a.ranges[e0 + b0 + i];       // {group start, length, own count}
-                s_gm[i] = make_uint2(rg.x, rg.z); len[j] = rg.y;
+                s_gm[i] = make_uint2(rg.x, rg.z); s_gsv[i] = rg.x + rg.y - rg.w; len[j] = rg.y;
             }
             sum += len[j];
         }
@@ -245,7 +250,7 @@ __global__ __launch_bounds__(T_) void k_join_lds(JoinArgs a) {
         for (; ch < ch_end; ch += 4) {
             if (*(volatile uint32_t *) &s_overflow) break;
             uint2 gm[4], po[4];
-            uint32_t adr[4];
+            uint32_t adr[4], gsv[4];
             bool live[4];
 #pragma unroll
             for (uint32_t u = 0; u < 4; u++) {
@@ -264,9 +269,10 @@ __global__ __launch_bounds__(T_) void k_join_lds(JoinArgs a) {
                     const uint32_t off = below ? lane - (63u - (uint32_t) __clzll((long long) below)) : f - cum_rs;
                     live[u] = f < total;
                     gm[u] = s_gm[r];
+                    gsv[u] = s_gsv[r];
                     adr[u] = gm[u].x + off;
                     // keep the invariant "rs holds the first lookup of the next chunk": a range may start exactly there
-                    const uint32_t nextb = __builtin_amdgcn_readlane(v, w);      // w <= 32: groups have >= 2 records
+                    const uint32_t nextb = w < PDL_WAVE ? __builtin_amdgcn_readlane(v, w) : s_cum[rs + 1 + PDL_WAVE];
                     if (nextb == f0 + PDL_WAVE) { rs += w + 1; cum_rs = nextb; }
                     else if (w) { cum_rs = __builtin_amdgcn_readlane(v, w - 1); rs += w; }
                 }
@@ -278,7 +284,7 @@ __global__ __launch_bounds__(T_) void k_join_lds(JoinArgs a) {
 #pragma unroll
                 for (uint32_t u = 0; u < 4; u++) if (live[u] && po[u].x == 0xfffffff0u) s_overflow = 1;
             } else {
-                fn4(po, gm, live);
+                fn4(po, gm, gsv, live);
             }
         }
     };
@@ -311,13 +317,13 @@ __global__ __launch_bounds__(T_) void k_join_lds(JoinArgs a) {
         if constexpr (!FILTER) {
             for (uint32_t b0 = 0; b0 < nr; b0 += RB) {
                 const uint32_t total = stage(e0, b0, min(RB, nr - b0));
-                walk(total, [&](const uint2 (&po)[4], const uint2 (&gm)[4], const bool (&live)[4]) {
+                walk(total, [&](const uint2 (&po)[4], const uint2 (&gm)[4], const uint32_t (&gsv)[4], const bool (&live)[4]) {
 #pragma unroll
                     for (uint32_t u = 0; u < 4; u++) {
                         if (!live[u] || *(volatile uint32_t *) &s_overflow) continue;   // <= 1 insertion per lane after the flag
                         uint32_t seen;
                         const uint32_t slot = find_or_insert(po[u].x, seen);
-                        add_to(slot, seen, po[u].y, gm[u].y, 0xffffffffu - gm[u].x);
+                        add_to(slot, seen, po[u].y, gm[u].y, 0xffffffffu - gsv[u]);
                     }
                 });
                 __syncthreads();
@@ -329,7 +335,7 @@ __global__ __launch_bounds__(T_) void k_join_lds(JoinArgs a) {
             uint32_t total = 0;
             for (uint32_t b0 = 0; b0 < nr; b0 += RB) {       // pass 1: which columns need a slot
                 total = stage(e0, b0, min(RB, nr - b0));     // (its barriers also cover the bitmap clear)
-                walk(total, [&](const uint2 (&po)[4], const uint2 (&gm)[4], const bool (&live)[4]) {
+                walk(total, [&](const uint2 (&po)[4], const uint2 (&gm)[4], const uint32_t (&)[4], const bool (&live)[4]) {
                     bool ins[4];
                     uint32_t old[4], bit[4];
 #pragma unroll
@@ -352,7 +358,7 @@ __global__ __launch_bounds__(T_) void k_join_lds(JoinArgs a) {
             if (!s_overflow) {
                 for (uint32_t b0 = 0; b0 < nr; b0 += RB) {   // pass 2: add every contribution of the kept columns
                     if (nr > RB) total = stage(e0, b0, min(RB, nr - b0));   // single batch: still staged
-                    walk(total, [&](const uint2 (&po)[4], const uint2 (&gm)[4], const bool (&live)[4]) {
+                    walk(total, [&](const uint2 (&po)[4], const uint2 (&gm)[4], const uint32_t (&gsv)[4], const bool (&live)[4]) {
                         uint32_t slot[4];
                         uint2 kf[4];
 #pragma unroll
@@ -364,7 +370,7 @@ __global__ __launch_bounds__(T_) void k_join_lds(JoinArgs a) {
                         for (uint32_t u = 0; u < 4; u++) {
                             if (!live[u]) continue;
                             for (;;) {
-                                if (kf[u].x == po[u].x) { add_to(slot[u], kf[u].y, po[u].y, gm[u].y, 0xffffffffu - gm[u].x); break; }
+                                if (kf[u].x == po[u].x) { add_to(slot[u], kf[u].y, po[u].y, gm[u].y, 0xffffffffu - gsv[u]); break; }
                                 if (kf[u].x == EMPTY_KEY) break;     // column was seen once only
                                 slot[u] = (slot[u] + 1) & (HT - 1);
                                 kf[u] = s_kf[slot[u]];
@@ -397,6 +403,7 @@ __global__ __launch_bounds__(T_) void k_join_lds(JoinArgs a) {
             s_base = nx;
         }
         const uint32_t pc_min = min_numerator(threshold, (float) (int) my_kcnt);
+        const uint32_t my_genome = a.genome_of[r];
         float *ms_row = a.MS + (size_t) p * a.G;
         float *cm_row = a.CM + (size_t) a.task_lg[p] * a.N;
         __syncthreads();
@@ -425,8 +432,18 @@ __global__ __launch_bounds__(T_) void k_join_lds(JoinArgs a) {
                     a.st_score[o] = score; a.st_perc[o] = perc; a.st_tr[o] = tr;
                     a.st_col[o] = c; a.st_first[o] = 0xffffffffu - kf.y;
                     // scores are positive floats: their bit patterns order like the values
-                    atomicMax(reinterpret_cast<uint32_t *>(ms_row + a.genome_of[c]), __float_as_uint(score));
+                    const uint32_t gc = a.genome_of[c];
+                    atomicMax(reinterpret_cast<uint32_t *>(ms_row + gc), __float_as_uint(score));
                     atomicMax(reinterpret_cast<uint32_t *>(cm_row + c), __float_as_uint(score));
+                    if (a.mirror) {
+                        // the same sums seen from gene c: cell (c, r) with perc and tr_perc swapped (both quotients
+                        // use the same integers the row program of c would have summed); K-order places it in c's row
+                        const uint32_t pc = a.taskpos_of[c];
+                        a.st_src[o] = r;
+                        atomicAdd(&a.mirror_cnt[pc], 1u);
+                        atomicMax(reinterpret_cast<uint32_t *>(a.MS + (size_t) pc * a.G + my_genome), __float_as_uint(score));
+                        atomicMax(reinterpret_cast<uint32_t *>(a.CM + (size_t) gc * a.N + r), __float_as_uint(score));
+                    }
                 }
             }
         }
@@ -479,8 +496,8 @@ __global__ __launch_bounds__(HBM_THREADS) void k_join_hbm(JoinArgs a) {
         // one wave per range; the whole workgroup strides over the long ones implicitly via wave count
         const uint32_t wave = tid / PDL_WAVE, lane = tid % PDL_WAVE, nwaves = JOIN_THREADS / PDL_WAVE;
         for (uint32_t e = e0 + wave; e < e1; e += nwaves) {
-            const uint4 rg = a.ranges[e];
-            const uint32_t finv = 0xffffffffu - rg.x;
+            const uint4 rg = a.ranges[e];                     // {first posting, postings, own count, group size}
+            const uint32_t finv = 0xffffffffu - (rg.x + rg.y - rg.w);   // group start
             for (uint32_t q = lane; q < rg.y; q += PDL_WAVE) {
                 const uint2 po = a.post[rg.x + q];
                 const uint32_t c = po.x;
@@ -529,8 +546,16 @@ __global__ __launch_bounds__(HBM_THREADS) void k_join_hbm(JoinArgs a) {
                 const unsigned long long o = base + i;
                 a.st_score[o] = score; a.st_perc[o] = perc; a.st_tr[o] = tr;
                 a.st_col[o] = c; a.st_first[o] = 0xffffffffu - ld_agent(&t_first[c]);
-                atomicMax(reinterpret_cast<uint32_t *>(ms_row + a.genome_of[c]), __float_as_uint(score));
+                const uint32_t gc = a.genome_of[c];
+                atomicMax(reinterpret_cast<uint32_t *>(ms_row + gc), __float_as_uint(score));
                 atomicMax(reinterpret_cast<uint32_t *>(cm_row + c), __float_as_uint(score));
+                if (a.mirror) {      // cell (c, r), see k_join_lds
+                    const uint32_t pc = a.taskpos_of[c];
+                    a.st_src[o] = r;
+                    atomicAdd(&a.mirror_cnt[pc], 1u);
+                    atomicMax(reinterpret_cast<uint32_t *>(a.MS + (size_t) pc * a.G + a.genome_of[r]), __float_as_uint(score));
+                    atomicMax(reinterpret_cast<uint32_t *>(a.CM + (size_t) gc * a.N + r), __float_as_uint(score));
+                }
             }
         }
         __syncthreads();
@@ -559,6 +584,8 @@ struct OrderArgs {
     const uint32_t *row_base, *row_cnt, *fin_off, *task_rows;
     const float *st_score, *st_perc, *st_tr;
     const uint32_t *st_col, *st_first;
+    // mirror mode: row p also owns mirror_cnt[p] cells that other rows staged; mirror_ref lists their staging slots
+    const uint32_t *st_src, *mirror_cnt, *mirror_off, *mirror_ref;
     float *c_score, *c_perc, *c_tr;
     int32_t *c_row, *c_col;
     uint32_t n_rows;
@@ -571,29 +598,43 @@ __device__ __forceinline__ unsigned long long order_key_hi(uint32_t col, uint32_
     return ((unsigned long long) chunk << 32) | first;
 }
 
+// cell i of row p: its own staged cells first, then the mirrored ones (a mirrored cell is the staged cell of
+// another row read with row/column and perc/tr_perc swapped)
+struct OrderCell { uint32_t slot; bool mirrored; };
+__device__ __forceinline__ OrderCell order_cell(const OrderArgs &a, uint32_t p, uint32_t own, uint32_t i) {
+    if (i < own) return OrderCell{a.row_base[p] + i, false};
+    return OrderCell{a.mirror_ref[a.mirror_off[p] + (i - own)], true};
+}
+
 __global__ __launch_bounds__(ORDER_THREADS) void k_order_rows(OrderArgs a) {
     __shared__ unsigned long long s_hi[ORDER_TILE];
     __shared__ uint32_t s_col[ORDER_TILE];
     const uint32_t p = blockIdx.x;
-    const uint32_t cnt = a.row_cnt[p];
+    const uint32_t own = a.row_cnt[p];
+    const uint32_t cnt = own + (a.mirror_cnt ? a.mirror_cnt[p] : 0u);
     if (cnt == 0) return;
-    const uint32_t base = a.row_base[p];
     const uint32_t out0 = a.fin_off[p];
     const uint32_t row = a.task_rows[p];
     for (uint32_t i0 = 0; i0 < cnt; i0 += ORDER_THREADS) {
         const uint32_t i = i0 + threadIdx.x;
         const bool live = i < cnt;
-        uint32_t col = 0, first = 0;
+        uint32_t col = 0;
         unsigned long long hi = 0;
-        if (live) { col = a.st_col[base + i]; first = a.st_first[base + i]; hi = order_key_hi(col, first, a.canonical); }
+        OrderCell me{0, false};
+        if (live) {
+            me = order_cell(a, p, own, i);
+            col = me.mirrored ? a.st_src[me.slot] : a.st_col[me.slot];
+            hi = order_key_hi(col, a.st_first[me.slot], a.canonical);
+        }
         uint32_t rank = 0;
         for (uint32_t j0 = 0; j0 < cnt; j0 += ORDER_TILE) {
             const uint32_t tn = min((uint32_t) ORDER_TILE, cnt - j0);
             __syncthreads();
             for (uint32_t j = threadIdx.x; j < tn; j += ORDER_THREADS) {
-                const uint32_t cj = a.st_col[base + j0 + j];
+                const OrderCell oc = order_cell(a, p, own, j0 + j);
+                const uint32_t cj = oc.mirrored ? a.st_src[oc.slot] : a.st_col[oc.slot];
                 s_col[j] = cj;
-                s_hi[j] = order_key_hi(cj, a.st_first[base + j0 + j], a.canonical);
+                s_hi[j] = order_key_hi(cj, a.st_first[oc.slot], a.canonical);
             }
             __syncthreads();
             if (live) {
@@ -605,12 +646,27 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_order_rows(OrderArgs a) {
         }
         if (live) {
             const uint32_t o = out0 + rank;
-            a.c_score[o] = a.st_score[base + i];
-            a.c_perc[o] = a.st_perc[base + i];
-            a.c_tr[o] = a.st_tr[base + i];
+            a.c_score[o] = a.st_score[me.slot];
+            a.c_perc[o] = me.mirrored ? a.st_tr[me.slot] : a.st_perc[me.slot];
+            a.c_tr[o] = me.mirrored ? a.st_perc[me.slot] : a.st_tr[me.slot];
             a.c_row[o] = (int32_t) row;
             a.c_col[o] = (int32_t) col;
         }
+    }
+}
+
+// mirror mode: hand every staged cell (r, c) to row c.  One wave per source row; the slot inside c's list is
+// drawn with an atomic (the order inside a list is irrelevant: K-order ranks the cells by key).
+__global__ __launch_bounds__(256) void k_mirror_refs(const uint32_t *__restrict__ row_base, const uint32_t *__restrict__ row_cnt,
+                                                     const uint32_t *__restrict__ st_col, const uint32_t *__restrict__ taskpos_of,
+                                                     const uint32_t *__restrict__ mirror_off, uint32_t *__restrict__ mirror_cur,
+                                                     uint32_t n_rows, uint32_t *__restrict__ mirror_ref) {
+    const uint32_t p = blockIdx.x * (256 / PDL_WAVE) + threadIdx.x / PDL_WAVE;
+    if (p >= n_rows) return;
+    const uint32_t base = row_base[p], cnt = row_cnt[p];
+    for (uint32_t i = threadIdx.x & (PDL_WAVE - 1); i < cnt; i += PDL_WAVE) {
+        const uint32_t pc = taskpos_of[st_col[base + i]];
+        mirror_ref[mirror_off[pc] + atomicAdd(&mirror_cur[pc], 1u)] = base + i;
     }
 }
 
@@ -637,8 +693,12 @@ __global__ __launch_bounds__(256) void k_row_desc_list(const uint32_t *__restric
 }
 
 struct RowCntFlag {
-    const uint32_t *row_cnt;
-    __device__ uint32_t operator()(uint64_t p) const { return row_cnt[p]; }
+    const uint32_t *row_cnt; const uint32_t *mirror_cnt;     // cells of a row = its own + the mirrored ones
+    __device__ uint32_t operator()(uint64_t p) const { return row_cnt[p] + (mirror_cnt ? mirror_cnt[p] : 0u); }
+};
+struct MirrorCntFlag {
+    const uint32_t *mirror_cnt;
+    __device__ uint32_t operator()(uint64_t p) const { return mirror_cnt[p]; }
 };
 struct FinOffApply {
     uint32_t *fin_off;
@@ -680,6 +740,7 @@ void pdl_run_score_all(pdl_ctx *c) {
     if (n_rows == 0) { c->scored = true; ev_end(c, EV_SCORE_TOTAL); return; }
 
     c->task_rows.alloc((size_t) n_rows * 4); c->task_lg.alloc((size_t) n_rows * 4);
+    c->h_task_rows_host = h_rows;
     PDL_HIP(hipMemcpyAsync(c->task_rows.p, h_rows.data(), (size_t) n_rows * 4, hipMemcpyHostToDevice, st));
     PDL_HIP(hipMemcpyAsync(c->task_lg.p, h_lg.data(), (size_t) n_rows * 4, hipMemcpyHostToDevice, st));
     PDL_HIP(hipStreamSynchronize(st));   // h_rows / h_lg go out of use below
@@ -692,6 +753,19 @@ void pdl_run_score_all(pdl_ctx *c) {
     hipLaunchKernelGGL(k_row_desc, dim3((n_rows + 255) / 256), dim3(256), 0, st, c->task_rows.as<uint32_t>(), c->seq_off.as<uint32_t>(),
                        n_rows, c->row_desc.as<uint4>());
     c->overflow_rows.alloc((size_t) n_rows * 4 * 2);     // list A (tier 1 -> 2) and list B (tier 2 -> 3)
+    // mirror mode (whole dataset on this device, ranges hold only the genes above the row): every staged cell
+    // (r, c) is also cell (c, r)
+    const bool mirror = c->upper_only;
+    if (mirror && (c->shard_set && c->shard.size() != G))
+        PDL_FAIL(PDL_ERR_STATE, "the dictionary was built for all genomes (upper-triangle ranges); a genome shard must be set before pdl_preprocess");
+    if (mirror) {
+        std::vector<uint32_t> h_tp((size_t) N, 0xffffffffu);
+        for (uint32_t p = 0; p < n_rows; p++) h_tp[c->h_task_rows_host[p]] = p;
+        c->taskpos_of.alloc((size_t) N * 4);
+        PDL_HIP(hipMemcpyAsync(c->taskpos_of.p, h_tp.data(), (size_t) N * 4, hipMemcpyHostToDevice, st));
+        PDL_HIP(hipStreamSynchronize(st));
+        c->mirror_cnt.alloc((size_t) n_rows * 4 * 3);    // counts | offsets | cursors
+    }
     c->row_desc2.alloc((size_t) n_rows * sizeof(uint4));
 
     int cus = 256;
@@ -737,6 +811,10 @@ void pdl_run_score_all(pdl_ctx *c) {
         if (cap >= 0xffffffffull) PDL_FAIL(PDL_ERR_UNSUPPORTED, "more than 2^32 emitted cells on one device: shard the genomes over more devices");
         c->st_cap = cap;
         c->st_score.alloc(cap * 4); c->st_perc.alloc(cap * 4); c->st_tr.alloc(cap * 4); c->st_col.alloc(cap * 4); c->st_first.alloc(cap * 4);
+        if (mirror) {
+            c->st_src.alloc(cap * 4);
+            PDL_HIP(hipMemsetAsync(c->mirror_cnt.p, 0, (size_t) n_rows * 4 * 3, st));
+        }
         PDL_HIP(hipMemsetAsync(c->MS.p, 0, (size_t) n_rows * G * sizeof(float), st));
         PDL_HIP(hipMemsetAsync(c->CM.p, 0, (size_t) S * N * sizeof(float), st));
         PDL_HIP(hipMemsetAsync(c->join_ctr.p, 0, 64, st));
@@ -752,6 +830,8 @@ void pdl_run_score_all(pdl_ctx *c) {
         a.row_base = c->row_base.as<uint32_t>(); a.row_cnt = c->row_cnt.as<uint32_t>();
         a.st_score = c->st_score.as<float>(); a.st_perc = c->st_perc.as<float>(); a.st_tr = c->st_tr.as<float>();
         a.st_col = c->st_col.as<uint32_t>(); a.st_first = c->st_first.as<uint32_t>(); a.st_cap = cap;
+        a.mirror = mirror ? 1u : 0u;
+        if (mirror) { a.st_src = c->st_src.as<uint32_t>(); a.taskpos_of = c->taskpos_of.as<uint32_t>(); a.mirror_cnt = c->mirror_cnt.as<uint32_t>(); }
         // counters: 0 cursor tier 1 | 1 rows for tier 2 | 2 cursor tier 2 | 3 rows for tier 3 | 4-5 cell cursor | 6 errors | 7 cursor tier 3
         uint32_t *ctr32 = c->join_ctr.as<uint32_t>();
         uint32_t *list_a = c->overflow_rows.as<uint32_t>(), *list_b = list_a + n_rows;
@@ -805,10 +885,12 @@ void pdl_run_score_all(pdl_ctx *c) {
     // ---- order ------------------------------------------------------------------------------------
     ev_begin(c, EV_ORDER);
     uint64_t *d_scal = c->scalars.as<uint64_t>();
-    scan_and_apply(c, n_rows, RowCntFlag{c->row_cnt.as<uint32_t>()}, FinOffApply{c->fin_off.as<uint32_t>()}, d_scal + 6);
+    const uint32_t *d_mcnt = mirror ? c->mirror_cnt.as<uint32_t>() : nullptr;
+    scan_and_apply(c, n_rows, RowCntFlag{c->row_cnt.as<uint32_t>(), d_mcnt}, FinOffApply{c->fin_off.as<uint32_t>()}, d_scal + 6);
     uint64_t zsum = 0;
     PDL_HIP(hipMemcpyAsync(&zsum, d_scal + 6, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     PDL_HIP(hipStreamSynchronize(st));
+    if (zsum >= 0xffffffffull) PDL_FAIL(PDL_ERR_UNSUPPORTED, "more than 2^32 emitted cells on one device");
     c->Z = zsum;
     c->tm.emitted_cells = c->Z;
     const uint32_t z32 = (uint32_t) c->Z;
@@ -816,6 +898,14 @@ void pdl_run_score_all(pdl_ctx *c) {
     const size_t zc = c->Z ? (size_t) c->Z : 1;
     c->c_score.alloc(zc * 4); c->c_perc.alloc(zc * 4); c->c_tr.alloc(zc * 4); c->c_row.alloc(zc * 4); c->c_col.alloc(zc * 4);
     OrderArgs o{};
+    if (mirror) {
+        uint32_t *m_off = c->mirror_cnt.as<uint32_t>() + n_rows, *m_cur = m_off + n_rows;
+        scan_and_apply(c, n_rows, MirrorCntFlag{d_mcnt}, FinOffApply{m_off}, d_scal + 9);
+        c->mirror_ref.alloc(zc * 4);
+        hipLaunchKernelGGL(k_mirror_refs, dim3((n_rows + 3) / 4), dim3(256), 0, st, c->row_base.as<uint32_t>(), c->row_cnt.as<uint32_t>(),
+                           c->st_col.as<uint32_t>(), c->taskpos_of.as<uint32_t>(), m_off, m_cur, n_rows, c->mirror_ref.as<uint32_t>());
+        o.st_src = c->st_src.as<uint32_t>(); o.mirror_cnt = d_mcnt; o.mirror_off = m_off; o.mirror_ref = c->mirror_ref.as<uint32_t>();
+    }
     o.row_base = c->row_base.as<uint32_t>(); o.row_cnt = c->row_cnt.as<uint32_t>(); o.fin_off = c->fin_off.as<uint32_t>();
     o.task_rows = c->task_rows.as<uint32_t>();
     o.st_score = c->st_score.as<float>(); o.st_perc = c->st_perc.as<float>(); o.st_tr = c->st_tr.as<float>();

@@ -1,0 +1,92 @@
+"""The host half after the native boundary (BBH filter + .net edge list).
+
+CPU: the product's array implementation (pandelos_amd/pangenes.py) against the loop-by-loop restatement of the Java
+(oracle/pangenes_host.py) and against the committed .net/.clus fixtures (tests/golden/net, produced with the reference's
+netclu_ng.py in the build container).  GPU: the whole path .faa -> .net on the device equals the fixture byte for byte,
+which makes the gene families (.clus) identical too.  NOTE: nothing of the reference pins the Java host (no JVM here, no
+reference tests): these fixtures pin our reading of it, not the Java itself."""
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from pandelos_amd import pangenes as PH
+from pandelos_amd.scores import Scores
+from pandelos_amd.synth import make_gene_set
+from tests import helpers as H
+
+NET = H.GOLDEN / "net"
+CASES = {
+    "synth_5x60x80_k3": (dict(genomes=5, genes_per_genome=60, mean_len=80, sub_rate=0.08, seed=1), 3),
+    "synth_8x300x200_k4_div25": (dict(genomes=8, genes_per_genome=300, mean_len=200, sub_rate=0.25, seed=11), 4),
+    "synth_12x100x100_k3_near_identical": (dict(genomes=12, genes_per_genome=100, mean_len=100, sub_rate=0.02, seed=5), 3),
+}
+
+
+class _OracleNative:
+    """Scores blocks from the CPU oracle, shaped like PangeneNative (test scaffolding)."""
+    def __init__(self, gs, k):
+        from oracle import binding as ob
+        self.o = ob.Oracle(gs.residues, gs.offsets, gs.genome_of, k)
+
+    def generate_scores_part(self, g, multithread=False):
+        d = self.o.scores(g)
+        return Scores(**{f: d[f] for f in ("scoresCount",) + H.FIELDS})
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_product_host_matches_oracle_host_and_fixture(name):
+    from oracle import pangenes_host as oh
+    shape, k = CASES[name]
+    gs = make_gene_set(**shape)
+    nat = _OracleNative(gs, k)
+    got = PH.run(nat, gs.genomes)
+    want = oh.build_net(lambda g: nat.o.scores(g), gs.genomes, gs.genes)
+    assert got == want
+    assert "".join(got) == (NET / f"{name}.net").read_text()
+
+
+def test_java_hashmap_order_and_double_format():
+    from oracle import pangenes_host as oh
+    # 13 keys -> capacity 32 (13 > 0.75*16); bucket = key & 31 for small keys; collisions keep insertion order
+    keys = [40, 8, 33, 1, 65, 2, 97, 3, 4, 5, 6, 7, 9]
+    assert oh.java_hashmap_key_order(keys) == [33, 1, 65, 97, 2, 3, 4, 5, 6, 7, 40, 8, 9]
+    lines = PH.net_lines(np.array(keys + [8], np.int64), np.array([100] * 13 + [100], np.int64),
+                         np.array([0.5] * 13 + [0.25], np.float32))
+    assert [int(l.split("\t")[0]) for l in lines] == [33, 1, 65, 97, 2, 3, 4, 5, 6, 7, 40, 8, 9]
+    assert lines[11] == "8\t100\t0.5\n"                         # first insert per (src, dst) wins
+    for v, s in [(0.849056601524353, "0.849056601524353"), (1.0, "1.0"), (0.00095, "9.5E-4"), (1e-4, "1.0E-4"),
+                 (0.001, "0.001"), (float(np.float32(1 / 3)), "0.3333333432674408")]:
+        assert oh.java_double_to_string(v) == s
+        assert PH._java_double_str(np.array([v], np.float64))[0] == s
+
+
+@pytest.mark.skipif(not Path("/root/reference/netclu_ng.py").exists(), reason="reference scripts not present")
+def test_clus_from_product_net_equals_fixture(tmp_path):
+    """pandelos.sh:76-79 on our .net: the reference's netclu_ng.py + grep/sed/sort/uniq."""
+    name = "synth_5x60x80_k3"
+    shape, k = CASES[name]
+    gs = make_gene_set(**shape)
+    faa, net = tmp_path / "in.faa", tmp_path / "out.net"
+    gs.write_faa(faa)
+    net.write_text("".join(PH.run(_OracleNative(gs, k), gs.genomes)))
+    p = subprocess.run([sys.executable, "/root/reference/netclu_ng.py", str(faa), str(net)], capture_output=True, text=True, check=True)
+    fams = sorted({l.replace("F{ ", "").replace("}", "").replace(" ;", "") for l in p.stdout.splitlines() if "F{ " in l})
+    assert "".join(f + "\n" for f in fams) == (NET / f"{name}.clus").read_text()
+    planted = {}
+    for i, f in enumerate(gs.family_of):
+        planted.setdefault(int(f), []).append(i)
+    assert len(fams) == len(planted)                              # every planted family comes back as one gene family
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_device_pipeline_writes_the_fixture_net(name, tmp_path):
+    shape, k = CASES[name]
+    gs = make_gene_set(**shape)
+    faa, net = tmp_path / "in.faa", tmp_path / "out.net"
+    gs.write_faa(faa)
+    assert PH.main(["-i", str(faa), "-k", str(k), "-o", str(net)]) == 0
+    assert net.read_text() == (NET / f"{name}.net").read_text()

@@ -92,7 +92,7 @@ static void build_genome_layout(pdl_ctx *c) {
 static int preprocess_common(pdl_ctx *c, uint32_t n, uint64_t n_res, int k, int only_complexity, pdl_cost *out_cost) {
     PDL_GUARD_BEGIN
     PDL_HIP(hipSetDevice(c->device));
-    c->preprocessed = false; c->scored = false;      // the genome shard, if one was set, stays in force
+    c->preprocessed = false; c->scored = false; c->tasks_ready = false;      // the genome shard, if one was set, stays in force
     c->N = n; c->R = n_res;
     c->U = c->Ushared = c->NG = c->P = c->M = 0;
     if (k <= 0) PDL_FAIL(PDL_ERR_KVALUE, "K value must be greater than 0.");
@@ -195,6 +195,7 @@ int pdl_set_genome_shard(pdl_ctx *c, const uint32_t *genomes, uint32_t count) {
     c->shard = std::move(s);
     c->shard_set = count != 0;
     c->scored = false;
+    c->tasks_ready = false;
     return PDL_OK;
 }
 

@@ -147,7 +147,11 @@ struct pdl_ctx {
     bool glb_clean = false;   // all-zero (k_join_hbm leaves them that way)
     DevBuf row_desc2;     // descriptors of the rows handed from tier 1 to tier 2
     DevBuf st_src, taskpos_of, mirror_cnt, mirror_ref;   // mirror mode (see pdl_join.hip)
-    std::vector<uint32_t> h_task_rows_host;
+    std::vector<uint32_t> h_task_rows_host, h_task_lg_host, h_taskpos_host, h_fin;
+    bool tasks_ready = false;  // task layout uploaded for the current shard
+    DevBuf scratch2;
+    int cus = 0;
+    uint32_t occ_tier1[3] = {0, 0, 0};
 
     pdl_timings tm{};
     EventPair ev[12];
@@ -156,6 +160,7 @@ struct pdl_ctx {
 // stage entry points (pdl_dict.hip / pdl_join.hip)
 void pdl_run_preprocess(pdl_ctx *c, int kvalue, bool only_complexity);
 void pdl_run_score_all(pdl_ctx *c);
+void pdl_prepare_tasks(pdl_ctx *c);
 
 // event helpers
 enum { EV_HIST, EV_RANK, EV_SORT1, EV_DICT, EV_SORT2, EV_RANGES, EV_JOIN, EV_JOIN_OVF, EV_ORDER, EV_PRE_TOTAL, EV_SCORE_TOTAL, EV_COUNT };

@@ -446,6 +446,7 @@ static void dictionary_pipeline(pdl_ctx *c, bool only_complexity) {
     ev_begin(c, EV_SORT1);
     pdl_sort_pairs<KeyT>(c, keys_in, keys_out, vals_in, vals_out, M, c->rp.rank_bits);
     ev_end(c, EV_SORT1);
+    if (!only_complexity) pdl_prepare_tasks(c);     // host work + small uploads while the device sorts
     // remember which physical buffers hold the sorted stream (pdl_get_dictionary reads them)
     if ((void *) keys_out != c->keys_b.p) { std::swap(c->keys_a.p, c->keys_b.p); std::swap(c->keys_a.bytes, c->keys_b.bytes); }
     if ((void *) vals_out != c->vals_b.p) { std::swap(c->vals_a.p, c->vals_b.p); std::swap(c->vals_a.bytes, c->vals_b.bytes); }

@@ -710,28 +710,55 @@ __global__ void k_gather_u32(const uint32_t *src, const uint32_t *idx, uint32_t 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Task layout of the shard on the host and its upload: shard genomes ascending, rows of a genome ascending
+// (library.cpp:244).  Called from the preprocess while the device is busy sorting, and again only if the shard
+// changed since.  The host vectors live in the context, so the asynchronous copies need no synchronisation here.
+void pdl_prepare_tasks(pdl_ctx *c) {
+    hipStream_t st = c->stream;
+    const uint32_t N = c->N, G = c->G;
+    if (!c->shard_set) { c->shard.resize(G); for (uint32_t g = 0; g < G; g++) c->shard[g] = g; }
+    const uint32_t S = (uint32_t) c->shard.size();
+    c->h_local_genome.assign(G, -1);
+    c->h_task_row_off.assign(S + 1, 0);
+    uint32_t n_rows = 0;
+    for (uint32_t i = 0; i < S; i++) n_rows += c->h_genome_row_off[c->shard[i] + 1] - c->h_genome_row_off[c->shard[i]];
+    c->h_task_rows_host.resize(n_rows);
+    c->h_task_lg_host.resize(n_rows);
+    uint32_t p = 0;
+    for (uint32_t i = 0; i < S; i++) {
+        const uint32_t g = c->shard[i];
+        c->h_local_genome[g] = (int32_t) i;
+        c->h_task_row_off[i] = p;
+        for (uint32_t j = c->h_genome_row_off[g]; j < c->h_genome_row_off[g + 1]; j++) { c->h_task_rows_host[p] = c->h_genome_rows[j]; c->h_task_lg_host[p] = i; p++; }
+    }
+    c->h_task_row_off[S] = n_rows;
+    c->n_task_rows = n_rows;
+    c->tasks_ready = true;
+    if (n_rows == 0) return;
+    c->task_rows.alloc((size_t) n_rows * 4); c->task_lg.alloc((size_t) n_rows * 4);
+    PDL_HIP(hipMemcpyAsync(c->task_rows.p, c->h_task_rows_host.data(), (size_t) n_rows * 4, hipMemcpyHostToDevice, st));
+    PDL_HIP(hipMemcpyAsync(c->task_lg.p, c->h_task_lg_host.data(), (size_t) n_rows * 4, hipMemcpyHostToDevice, st));
+    if (!c->shard_set || S == G) {         // whole dataset: every gene has a task position (mirror mode needs the map)
+        c->h_taskpos_host.assign((size_t) N, 0xffffffffu);
+        for (uint32_t q = 0; q < n_rows; q++) c->h_taskpos_host[c->h_task_rows_host[q]] = q;
+        c->taskpos_of.alloc((size_t) N * 4);
+        PDL_HIP(hipMemcpyAsync(c->taskpos_of.p, c->h_taskpos_host.data(), (size_t) N * 4, hipMemcpyHostToDevice, st));
+    }
+    c->scratch2.alloc((size_t) (S + 1) * 8);
+    PDL_HIP(hipMemcpyAsync(c->scratch2.p, c->h_task_row_off.data(), (size_t) (S + 1) * 4, hipMemcpyHostToDevice, st));
+}
+
+__global__ void k_set_u32_from_u64(uint32_t *dst, const uint64_t *src) { *dst = (uint32_t) *src; }
+
 void pdl_run_score_all(pdl_ctx *c) {
     hipStream_t st = c->stream;
     const uint32_t N = c->N, G = c->G;
     if (c->max_kseq >= (1ull << 20))
         PDL_FAIL(PDL_ERR_UNSUPPORTED, "a gene with %llu k-mers exceeds the 2^20 limit of the packed accumulators", (unsigned long long) c->max_kseq);
     ev_begin(c, EV_SCORE_TOTAL);
-
-    // ---- task layout: shard genomes ascending, rows of a genome ascending (library.cpp:244) ----
-    if (!c->shard_set) { c->shard.resize(G); for (uint32_t g = 0; g < G; g++) c->shard[g] = g; }
+    if (!c->tasks_ready) pdl_prepare_tasks(c);
     const uint32_t S = (uint32_t) c->shard.size();
-    c->h_local_genome.assign(G, -1);
-    c->h_task_row_off.assign(S + 1, 0);
-    std::vector<uint32_t> h_rows, h_lg;
-    for (uint32_t i = 0; i < S; i++) {
-        const uint32_t g = c->shard[i];
-        c->h_local_genome[g] = (int32_t) i;
-        c->h_task_row_off[i] = (uint32_t) h_rows.size();
-        for (uint32_t j = c->h_genome_row_off[g]; j < c->h_genome_row_off[g + 1]; j++) { h_rows.push_back(c->h_genome_rows[j]); h_lg.push_back(i); }
-    }
-    c->h_task_row_off[S] = (uint32_t) h_rows.size();
-    const uint32_t n_rows = (uint32_t) h_rows.size();
-    c->n_task_rows = n_rows;
+    const uint32_t n_rows = c->n_task_rows;
     c->h_cell_off.assign(S + 1, 0);
     c->Z = 0;
     c->tm.emitted_cells = 0; c->tm.scored_rows = n_rows; c->tm.overflow_rows = 0; c->tm.join_launches = 0;
@@ -739,44 +766,38 @@ void pdl_run_score_all(pdl_ctx *c) {
     for (uint32_t i = 0; i < S; i++) c->tm.scored_lookups += c->h_genome_cost[c->shard[i]];
     if (n_rows == 0) { c->scored = true; ev_end(c, EV_SCORE_TOTAL); return; }
 
-    c->task_rows.alloc((size_t) n_rows * 4); c->task_lg.alloc((size_t) n_rows * 4);
-    c->h_task_rows_host = h_rows;
-    PDL_HIP(hipMemcpyAsync(c->task_rows.p, h_rows.data(), (size_t) n_rows * 4, hipMemcpyHostToDevice, st));
-    PDL_HIP(hipMemcpyAsync(c->task_lg.p, h_lg.data(), (size_t) n_rows * 4, hipMemcpyHostToDevice, st));
-    PDL_HIP(hipStreamSynchronize(st));   // h_rows / h_lg go out of use below
+    // mirror mode (whole dataset on this device, ranges hold only the genes above the row): every staged cell
+    // (r, c) is also cell (c, r)
+    const bool mirror = c->upper_only;
+    if (mirror && (c->shard_set && S != G))
+        PDL_FAIL(PDL_ERR_STATE, "the dictionary was built for all genomes (upper-triangle ranges); a genome shard must be set before pdl_preprocess");
 
     c->MS.alloc((size_t) n_rows * G * sizeof(float));
     c->CM.alloc((size_t) S * N * sizeof(float));
     c->row_base.alloc((size_t) n_rows * 4); c->row_cnt.alloc((size_t) n_rows * 4); c->fin_off.alloc(((size_t) n_rows + 1) * 4);
     c->join_ctr.alloc(64);
     c->row_desc.alloc((size_t) n_rows * sizeof(uint4));
+    c->row_desc2.alloc((size_t) n_rows * sizeof(uint4));
+    c->overflow_rows.alloc((size_t) n_rows * 4 * 2);     // list A (tier 1 -> 2) and list B (tier 2 -> 3)
+    if (mirror) c->mirror_cnt.alloc((size_t) n_rows * 4 * 3);    // counts | offsets | cursors
     hipLaunchKernelGGL(k_row_desc, dim3((n_rows + 255) / 256), dim3(256), 0, st, c->task_rows.as<uint32_t>(), c->seq_off.as<uint32_t>(),
                        n_rows, c->row_desc.as<uint4>());
-    c->overflow_rows.alloc((size_t) n_rows * 4 * 2);     // list A (tier 1 -> 2) and list B (tier 2 -> 3)
-    // mirror mode (whole dataset on this device, ranges hold only the genes above the row): every staged cell
-    // (r, c) is also cell (c, r)
-    const bool mirror = c->upper_only;
-    if (mirror && (c->shard_set && c->shard.size() != G))
-        PDL_FAIL(PDL_ERR_STATE, "the dictionary was built for all genomes (upper-triangle ranges); a genome shard must be set before pdl_preprocess");
-    if (mirror) {
-        std::vector<uint32_t> h_tp((size_t) N, 0xffffffffu);
-        for (uint32_t p = 0; p < n_rows; p++) h_tp[c->h_task_rows_host[p]] = p;
-        c->taskpos_of.alloc((size_t) N * 4);
-        PDL_HIP(hipMemcpyAsync(c->taskpos_of.p, h_tp.data(), (size_t) N * 4, hipMemcpyHostToDevice, st));
-        PDL_HIP(hipStreamSynchronize(st));
-        c->mirror_cnt.alloc((size_t) n_rows * 4 * 3);    // counts | offsets | cursors
-    }
-    c->row_desc2.alloc((size_t) n_rows * sizeof(uint4));
 
-    int cus = 256;
-    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) cus = prop.multiProcessorCount; }
+    int cus = c->cus;
+    if (cus <= 0) {
+        cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) cus = prop.multiProcessorCount;
+        c->cus = cus;
+    }
 
     // ---- tiers ---------------------------------------------------------------------------------------
     //   1  k_join_lds<FILTER>     small table + "seen twice" bitmap, several rows resident per CU
     //   2  k_join_lds<13,1024>    128-KiB table holding every column a row touches, one row per CU
     //   3  k_join_hbm             direct-addressed tables in HBM
-    // A tier hands the rows it cannot hold to the next one through a device-side list; the three launches are
-    // queued back to back and the counters are read once at the end.
+    // A tier hands the rows it cannot hold to the next one through a device-side list; the launches of the three
+    // tiers, the emission-order pass and the per-genome offsets are queued back to back and the host looks at the
+    // counters once, at the end (a staging area that turns out too small repeats the pass).
     // PDL_JOIN_TIER1 = 0 | 9 | 10 | 11 picks the tier-1 table (0: skip tier 1); PDL_JOIN_TABLE_BITS=9 swaps
     // tier 2 for a tiny table so that tests can reach tier 3 with small inputs.
     int tier1 = G <= 320 ? 10 : 11;     // keys per row ~ homologs (about one per genome) + repeated/colliding noise
@@ -791,7 +812,8 @@ void pdl_run_score_all(pdl_ctx *c) {
     const void *fn1 = tier1 == 9 ? (const void *) k_join_lds<9, 128, true>
                     : tier1 == 10 ? (const void *) k_join_lds<10, 256, true> : (const void *) k_join_lds<11, 256, true>;
     const int t1_threads = tier1 == 9 ? 128 : 256;
-    const uint32_t grid1 = tier1 ? std::min<uint32_t>(n_rows, (uint32_t) cus * occupancy(fn1, t1_threads)) : 0;
+    if (tier1 && c->occ_tier1[tier1 - 9] == 0) c->occ_tier1[tier1 - 9] = occupancy(fn1, t1_threads);
+    const uint32_t grid1 = tier1 ? std::min<uint32_t>(n_rows, (uint32_t) cus * c->occ_tier1[tier1 - 9]) : 0;
     const uint32_t grid2 = std::min<uint32_t>(n_rows, (uint32_t) cus * (tiny_tier2 ? 4 : 1));
     const uint32_t grid3 = (uint32_t) std::min<int>(cus, 64);
     const size_t hbm_bytes = (size_t) grid3 * N * (sizeof(uint64_t) + 3 * sizeof(uint32_t));
@@ -807,12 +829,16 @@ void pdl_run_score_all(pdl_ctx *c) {
     const unsigned long long slack = 2ull * (grid1 + grid2 + grid3) * CELL_CHUNK;
     unsigned long long cap = std::max<unsigned long long>(1ull << 20, (unsigned long long) n_rows * (G + 16ull));
     cap = std::min<unsigned long long>(cap, std::max<unsigned long long>(c->P, 1ull)) + slack;
+    uint64_t *d_scal = c->scalars.as<uint64_t>();
     for (int attempt = 0; attempt < 2; attempt++) {
-        if (cap >= 0xffffffffull) PDL_FAIL(PDL_ERR_UNSUPPORTED, "more than 2^32 emitted cells on one device: shard the genomes over more devices");
+        const unsigned long long fcap = mirror ? 2 * cap : cap;          // final cells: staged ones + their mirrors
+        if (fcap >= 0xffffffffull) PDL_FAIL(PDL_ERR_UNSUPPORTED, "more than 2^32 emitted cells on one device: shard the genomes over more devices");
         c->st_cap = cap;
         c->st_score.alloc(cap * 4); c->st_perc.alloc(cap * 4); c->st_tr.alloc(cap * 4); c->st_col.alloc(cap * 4); c->st_first.alloc(cap * 4);
+        c->c_score.alloc(fcap * 4); c->c_perc.alloc(fcap * 4); c->c_tr.alloc(fcap * 4); c->c_row.alloc(fcap * 4); c->c_col.alloc(fcap * 4);
         if (mirror) {
             c->st_src.alloc(cap * 4);
+            c->mirror_ref.alloc(cap * 4);
             PDL_HIP(hipMemsetAsync(c->mirror_cnt.p, 0, (size_t) n_rows * 4 * 3, st));
         }
         PDL_HIP(hipMemsetAsync(c->MS.p, 0, (size_t) n_rows * G * sizeof(float), st));
@@ -869,66 +895,57 @@ void pdl_run_score_all(pdl_ctx *c) {
         ev_end(c, EV_JOIN_OVF);
         c->tm.join_launches += 3;
 
+        // ---- order ----------------------------------------------------------------------------------
+        ev_begin(c, EV_ORDER);
+        const uint32_t *d_mcnt = mirror ? c->mirror_cnt.as<uint32_t>() : nullptr;
+        scan_and_apply(c, n_rows, RowCntFlag{c->row_cnt.as<uint32_t>(), d_mcnt}, FinOffApply{c->fin_off.as<uint32_t>()}, d_scal + 6);
+        hipLaunchKernelGGL(k_set_u32_from_u64, dim3(1), dim3(1), 0, st, c->fin_off.as<uint32_t>() + n_rows, d_scal + 6);
+        OrderArgs o{};
+        if (mirror) {
+            uint32_t *m_off = c->mirror_cnt.as<uint32_t>() + n_rows, *m_cur = m_off + n_rows;
+            scan_and_apply(c, n_rows, MirrorCntFlag{d_mcnt}, FinOffApply{m_off}, d_scal + 9);
+            hipLaunchKernelGGL(k_mirror_refs, dim3((n_rows + 3) / 4), dim3(256), 0, st, c->row_base.as<uint32_t>(), c->row_cnt.as<uint32_t>(),
+                               c->st_col.as<uint32_t>(), c->taskpos_of.as<uint32_t>(), m_off, m_cur, n_rows, c->mirror_ref.as<uint32_t>());
+            o.st_src = c->st_src.as<uint32_t>(); o.mirror_cnt = d_mcnt; o.mirror_off = m_off; o.mirror_ref = c->mirror_ref.as<uint32_t>();
+        }
+        o.row_base = c->row_base.as<uint32_t>(); o.row_cnt = c->row_cnt.as<uint32_t>(); o.fin_off = c->fin_off.as<uint32_t>();
+        o.task_rows = c->task_rows.as<uint32_t>();
+        o.st_score = c->st_score.as<float>(); o.st_perc = c->st_perc.as<float>(); o.st_tr = c->st_tr.as<float>();
+        o.st_col = c->st_col.as<uint32_t>(); o.st_first = c->st_first.as<uint32_t>();
+        o.c_score = c->c_score.as<float>(); o.c_perc = c->c_perc.as<float>(); o.c_tr = c->c_tr.as<float>();
+        o.c_row = c->c_row.as<int32_t>(); o.c_col = c->c_col.as<int32_t>();
+        o.n_rows = n_rows; o.canonical = (c->flags & PDL_FLAG_CANONICAL_ORDER) ? 1u : 0u;
+        hipLaunchKernelGGL(k_order_rows, dim3(n_rows), dim3(ORDER_THREADS), 0, st, o);
+        PDL_HIP(hipGetLastError());
+        ev_end(c, EV_ORDER);
+
+        // first cell of every shard genome = fin_off at its first task row; then the one look at the counters
+        uint32_t *d_idx = c->scratch2.as<uint32_t>();
+        uint32_t *d_out = d_idx + (S + 1);
+        hipLaunchKernelGGL(k_gather_u32, dim3((S + 1 + 255) / 256), dim3(256), 0, st, c->fin_off.as<uint32_t>(), d_idx, S + 1, d_out);
+        c->h_fin.resize(S + 1);
         uint32_t h_ctr[8];
+        uint64_t zsum = 0;
+        PDL_HIP(hipMemcpyAsync(c->h_fin.data(), d_out, (size_t) (S + 1) * 4, hipMemcpyDeviceToHost, st));
         PDL_HIP(hipMemcpyAsync(h_ctr, c->join_ctr.p, sizeof(h_ctr), hipMemcpyDeviceToHost, st));
+        PDL_HIP(hipMemcpyAsync(&zsum, d_scal + 6, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        ev_end(c, EV_SCORE_TOTAL);
         PDL_HIP(hipStreamSynchronize(st));
         c->glb_clean = true;
         c->tm.overflow_rows = h_ctr[3];
         c->tm.tier2_rows = tier1 ? h_ctr[1] : n_rows;
         if (h_ctr[6]) PDL_FAIL(PDL_ERR_DEVICE, "join: %u internal consistency violations", h_ctr[6]);
-        unsigned long long z;                    // staging cells reserved (>= cells emitted: chunk tails are unused)
+        unsigned long long z;                    // staging cells reserved (>= cells staged: chunk tails are unused)
         memcpy(&z, &h_ctr[4], sizeof(z));
-        if (z <= cap) break;
+        if (z <= cap) {
+            c->Z = zsum;
+            c->tm.emitted_cells = c->Z;
+            for (uint32_t i = 0; i <= S; i++) c->h_cell_off[i] = c->h_fin[i];
+            break;
+        }
         if (attempt == 1) PDL_FAIL(PDL_ERR_DEVICE, "staging overflow persisted (%llu cells > %llu)", z, cap);
         cap = z + slack;      // what was asked for plus chunk slack, second and last attempt
-    }
-    // ---- order ------------------------------------------------------------------------------------
-    ev_begin(c, EV_ORDER);
-    uint64_t *d_scal = c->scalars.as<uint64_t>();
-    const uint32_t *d_mcnt = mirror ? c->mirror_cnt.as<uint32_t>() : nullptr;
-    scan_and_apply(c, n_rows, RowCntFlag{c->row_cnt.as<uint32_t>(), d_mcnt}, FinOffApply{c->fin_off.as<uint32_t>()}, d_scal + 6);
-    uint64_t zsum = 0;
-    PDL_HIP(hipMemcpyAsync(&zsum, d_scal + 6, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    PDL_HIP(hipStreamSynchronize(st));
-    if (zsum >= 0xffffffffull) PDL_FAIL(PDL_ERR_UNSUPPORTED, "more than 2^32 emitted cells on one device");
-    c->Z = zsum;
-    c->tm.emitted_cells = c->Z;
-    const uint32_t z32 = (uint32_t) c->Z;
-    PDL_HIP(hipMemcpyAsync(c->fin_off.as<uint32_t>() + n_rows, &z32, 4, hipMemcpyHostToDevice, st));
-    const size_t zc = c->Z ? (size_t) c->Z : 1;
-    c->c_score.alloc(zc * 4); c->c_perc.alloc(zc * 4); c->c_tr.alloc(zc * 4); c->c_row.alloc(zc * 4); c->c_col.alloc(zc * 4);
-    OrderArgs o{};
-    if (mirror) {
-        uint32_t *m_off = c->mirror_cnt.as<uint32_t>() + n_rows, *m_cur = m_off + n_rows;
-        scan_and_apply(c, n_rows, MirrorCntFlag{d_mcnt}, FinOffApply{m_off}, d_scal + 9);
-        c->mirror_ref.alloc(zc * 4);
-        hipLaunchKernelGGL(k_mirror_refs, dim3((n_rows + 3) / 4), dim3(256), 0, st, c->row_base.as<uint32_t>(), c->row_cnt.as<uint32_t>(),
-                           c->st_col.as<uint32_t>(), c->taskpos_of.as<uint32_t>(), m_off, m_cur, n_rows, c->mirror_ref.as<uint32_t>());
-        o.st_src = c->st_src.as<uint32_t>(); o.mirror_cnt = d_mcnt; o.mirror_off = m_off; o.mirror_ref = c->mirror_ref.as<uint32_t>();
-    }
-    o.row_base = c->row_base.as<uint32_t>(); o.row_cnt = c->row_cnt.as<uint32_t>(); o.fin_off = c->fin_off.as<uint32_t>();
-    o.task_rows = c->task_rows.as<uint32_t>();
-    o.st_score = c->st_score.as<float>(); o.st_perc = c->st_perc.as<float>(); o.st_tr = c->st_tr.as<float>();
-    o.st_col = c->st_col.as<uint32_t>(); o.st_first = c->st_first.as<uint32_t>();
-    o.c_score = c->c_score.as<float>(); o.c_perc = c->c_perc.as<float>(); o.c_tr = c->c_tr.as<float>();
-    o.c_row = c->c_row.as<int32_t>(); o.c_col = c->c_col.as<int32_t>();
-    o.n_rows = n_rows; o.canonical = (c->flags & PDL_FLAG_CANONICAL_ORDER) ? 1u : 0u;
-    hipLaunchKernelGGL(k_order_rows, dim3(n_rows), dim3(ORDER_THREADS), 0, st, o);
-    PDL_HIP(hipGetLastError());
-    ev_end(c, EV_ORDER);
-
-    // first cell of every shard genome = fin_off at its first task row
-    {
-        std::vector<uint32_t> h_fin(S + 1);
-        c->scratch.alloc((size_t) (S + 1) * 8);
-        uint32_t *d_idx = c->scratch.as<uint32_t>();
-        uint32_t *d_out = d_idx + (S + 1);
-        PDL_HIP(hipMemcpyAsync(d_idx, c->h_task_row_off.data(), (size_t) (S + 1) * 4, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_gather_u32, dim3((S + 1 + 255) / 256), dim3(256), 0, st, c->fin_off.as<uint32_t>(), d_idx, S + 1, d_out);
-        PDL_HIP(hipMemcpyAsync(h_fin.data(), d_out, (size_t) (S + 1) * 4, hipMemcpyDeviceToHost, st));
-        ev_end(c, EV_SCORE_TOTAL);
-        PDL_HIP(hipStreamSynchronize(st));
-        for (uint32_t i = 0; i <= S; i++) c->h_cell_off[i] = h_fin[i];
+        ev_begin(c, EV_SCORE_TOTAL);
     }
     c->tm.join_ms = ev_ms(c, EV_JOIN);
     c->tm.join_overflow_ms = ev_ms(c, EV_JOIN_OVF);

@@ -173,6 +173,21 @@ def main():
     bytes_alg_total = (cost.residues + 16.0 * cost.kmer_occurrences + 16.0 * cost.dictionary_records +
                        8.0 * p_total + 20.0 * z_total + 8.0 * n_genes * n_genomes)
 
+    # HBM-side traffic of the join launch from the committed PMC profile of this workload (FETCH_SIZE / WRITE_SIZE
+    # are collected in separate rocprofv3 --pmc passes, corrected as MI355X_MICROARCH.md prescribes; see
+    # profiles/*_pmc_traffic_join.json).  null when no profile of this workload/sharding is on file.
+    traffic = None
+    if n_gpus == 1 and not args.faa:
+        for pf in sorted((ROOT / "profiles").glob("*_pmc_traffic_join.json"), reverse=True):
+            try:
+                prof = json.loads(pf.read_text())
+                if prof.get("workload") == args.config:
+                    traffic = sum(v.get("hbm_bytes_per_launch_corrected", 0.0) for kname, v in prof["kernels"].items()
+                                  if "k_join" in kname)
+                    break
+            except Exception:
+                pass
+
     out = {
         "metric": "scored gene-pairs/sec (whole node)",
         "value": pairs / sec_per_step,
@@ -197,7 +212,7 @@ def main():
                      "join_overflow": tm["join_overflow_ms"], "order": tm["order_ms"],
                      "tier2_rows": tm["tier2_rows"], "overflow_rows": tm["overflow_rows"]},
         "roofline": {"bound": "hbm", "kernel": "k_join_lds (+k_join_hbm)", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "bytes_per_launch": join_bytes, "launch_ms": join_s * 1e3},
     }
     nat.close()

@@ -30,7 +30,6 @@ def java_double_to_string(x: float) -> str:
         return "-0.0" if math.copysign(1.0, x) < 0 else "0.0"
     sign = "-" if x < 0 else ""
     ax = abs(x)
-    mant, exp = f"{ax:.17e}".split("e")          # placeholder to get the decimal exponent
     digits = repr(ax)                             # shortest round-trip digits
     # normalise repr to (digit string, decimal exponent)
     if "e" in digits:

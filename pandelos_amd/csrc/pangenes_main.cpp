@@ -1,0 +1,208 @@
+// pangenes_main.cpp — native host over the C ABI: what `java … infoasys.cli.pangenes.Pangenes -i in.faa -k K -o out.net`
+// does (pandelos.sh:73), for machines without a JVM.
+//
+//   ig/infoasys/cli/pangenes/Cli.java:13-57          flags -i/--input -k/--kvalue -o/--output (required), -c/--complexity,
+//                                                    -j/--threads (accepted, unused: the device pass is not threaded), -h
+//   ig/infoasys/cli/pangenes/PangeneIData.java:30-75 .faa reader (trim, skip blank lines, header/sequence alternate,
+//                                                    genome ids in first-seen order)
+//   ig/infoasys/cli/pangenes/Pangenes.java:60-183    per-genome task: bidirectional-best-hit filter, both phases
+//   ig/infoasys/cli/pangenes/PangeneNet.java:49-62,159-179   first insert per (src,dst) wins; undirected save in
+//                                                    java.util.HashMap iteration order, edges by ascending destination
+// Single-thread order (-j 1).  The same logic exists as array code in pandelos_amd/pangenes.py; tests compare both with
+// oracle/pangenes_host.py.  Nothing of the reference pins the Java host (no JVM in the build image, no reference tests).
+#include "../../include/pandelos_amd.h"
+
+#include <algorithm>
+#include <charconv>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <limits>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+std::string java_trim(const std::string &s) {       // String.trim(): strips chars <= ' ' at both ends
+    size_t b = 0, e = s.size();
+    while (b < e && (unsigned char) s[b] <= ' ') b++;
+    while (e > b && (unsigned char) s[e - 1] <= ' ') e--;
+    return s.substr(b, e - b);
+}
+
+// Double.toString of a float widened to double: shortest round-trip digits; decimal layout for 1e-3 <= x < 1e7,
+// "d.dddE-n" otherwise
+std::string java_double(double x) {
+    if (x == 0) return "0.0";
+    char buf[64];
+    auto r = std::to_chars(buf, buf + sizeof(buf), x, std::chars_format::scientific);
+    std::string sci(buf, r.ptr);                     // d[.ddd]e[+-]XX
+    const size_t epos = sci.find('e');
+    std::string mant = sci.substr(0, epos);
+    const int e10 = atoi(sci.c_str() + epos + 1);
+    std::string digits;
+    for (char ch : mant) if (ch != '.' && ch != '-') digits.push_back(ch);
+    const std::string sign = x < 0 ? "-" : "";
+    const double ax = std::fabs(x);
+    if (ax >= 1e-3 && ax < 1e7) {
+        std::string ip, fp;
+        if (e10 >= 0) {
+            ip = digits.substr(0, std::min<size_t>(digits.size(), (size_t) e10 + 1));
+            ip.append((size_t) e10 + 1 - ip.size(), '0');
+            fp = digits.size() > (size_t) e10 + 1 ? digits.substr((size_t) e10 + 1) : "0";
+        } else {
+            ip = "0";
+            fp = std::string((size_t) (-e10 - 1), '0') + digits;
+        }
+        return sign + ip + "." + fp;
+    }
+    return sign + digits.substr(0, 1) + "." + (digits.size() > 1 ? digits.substr(1) : "0") + "E" + std::to_string(e10);
+}
+
+struct Net {                                         // PangeneNet.java:38-62
+    std::unordered_map<int32_t, size_t> index;       // src -> position in keys (insertion order of the map keys)
+    std::vector<int32_t> keys;
+    std::vector<std::map<int32_t, float>> edges;     // TreeSet<Edge> keyed by destination
+    void add(int32_t src, int32_t dst, float score) {
+        auto it = index.find(src);
+        if (it == index.end()) { index.emplace(src, keys.size()); keys.push_back(src); edges.emplace_back(); it = index.find(src); }
+        edges[it->second].emplace(dst, score);       // first insert wins
+    }
+};
+
+void usage() {
+    printf("usage: PanDelos [OPTIONS]\n"
+           " -c,--complexity      Compute the required number of operations without computing the network (fast)\n"
+           " -h,--help            Print this help message\n"
+           " -i,--input <arg>     Input file (.faa) to process\n"
+           " -j,--threads <arg>   Number of threads to use for the computation, defaults to # of processors\n"
+           " -k,--kvalue <arg>    Length of the kmers used by the algorithm\n"
+           " -o,--output <arg>    Output file for the network\n");
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    std::string input, output;
+    int k = 0;
+    bool have_k = false, complexity = false;
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        auto val = [&]() -> const char * { return i + 1 < argc ? argv[++i] : nullptr; };
+        if (a == "-h" || a == "--help") { usage(); return 0; }
+        else if (a == "-c" || a == "--complexity") complexity = true;
+        else if (a == "-i" || a == "--input") { const char *v = val(); if (v) input = v; }
+        else if (a == "-o" || a == "--output") { const char *v = val(); if (v) output = v; }
+        else if (a == "-k" || a == "--kvalue") { const char *v = val(); if (v) { k = atoi(v); have_k = true; } }
+        else if (a == "-j" || a == "--threads") { (void) val(); }
+        else { input.clear(); break; }
+    }
+    if (input.empty() || output.empty() || !have_k) {           // Cli.java:83-87
+        printf("Error while parsing cli arguments!\n");
+        usage();
+        return 1;
+    }
+
+    // ---- PangeneIData.readFromFile ----------------------------------------------------------------------
+    std::vector<uint8_t> residues;
+    std::vector<uint64_t> offsets(1, 0);
+    std::vector<uint32_t> genome_of;
+    std::unordered_map<std::string, uint32_t> genome_id;
+    {
+        std::ifstream in(input);
+        if (!in) { fprintf(stderr, "java.io.FileNotFoundException: %s\n", input.c_str()); return 0; }   // Pangenes.java:26-31
+        std::string line, genome;
+        bool name_line = true;
+        while (std::getline(in, line)) {
+            if (!line.empty() && line.back() == '\r') line.pop_back();
+            const std::string t = java_trim(line);
+            if (t.empty()) continue;
+            if (name_line) {
+                genome = t.substr(0, t.find('\t'));
+            } else {
+                residues.insert(residues.end(), t.begin(), t.end());
+                offsets.push_back(residues.size());
+                auto it = genome_id.find(genome);
+                if (it == genome_id.end()) it = genome_id.emplace(genome, (uint32_t) genome_id.size()).first;
+                genome_of.push_back(it->second);
+            }
+            name_line = !name_line;
+        }
+    }
+    const uint32_t n = (uint32_t) genome_of.size();
+    const uint32_t G = (uint32_t) genome_id.size();
+
+    pdl_ctx *ctx = pdl_create(nullptr);
+    if (!ctx) { fprintf(stderr, "pandelos_amd: %s\n", pdl_last_error(nullptr)); return 1; }
+    if (k <= 0) { printf("K value must be greater than 0."); return 1; }      // library.cpp:90-93
+    pdl_cost cost;
+    if (pdl_preprocess(ctx, residues.data(), offsets.data(), genome_of.data(), n, k, complexity ? 1 : 0, &cost) != PDL_OK) {
+        fprintf(stderr, "pandelos_amd: %s\n", pdl_last_error(ctx));
+        return 1;
+    }
+    if (cost.hash_fallback) printf("Hashing fallback!\n");
+    printf("------------\nCOMPUTATIONAL COSTS: \nTotal cost: %llu lookups\nLinear ratio: %g\n------------\n\n",
+           (unsigned long long) cost.total_cost, (double) cost.linear_ratio);
+    if (complexity) { pdl_destroy(ctx); return 0; }                           // Pangenes.java:33-36
+
+    // ---- per-genome tasks, Pangenes.java:60-183 ------------------------------------------------------------
+    Net net;
+    for (uint32_t g = 0; g < G; g++) {
+        pdl_scores s;
+        if (pdl_compute_scores(ctx, g, &s) != PDL_OK) { fprintf(stderr, "pandelos_amd: %s\n", pdl_last_error(ctx)); return 1; }
+        uint64_t gcost = 0;
+        (void) pdl_genome_cost(ctx, g, &gcost);
+        printf("Genome %u cost = %llu\nFiltered count: %u\n", g, (unsigned long long) gcost, s.scoresCount);   // library.cpp:535-538, Pangenes.java:68
+        const uint32_t z = s.scoresCount;
+        std::vector<float> inter_max(G, 0.0f);
+        std::vector<uint8_t> should_add(z, 0);
+        for (uint32_t i = 0; i < z; i++) {                                    // :98-128
+            if (s.first_seq_genome[i] == s.second_seq_genome[i]) continue;
+            const float sc = s.scores[i];
+            if (sc == s.max_genome_score[(size_t) s.scoresMaxMappings[s.row[i]] * G + s.second_seq_genome[i]] &&
+                sc == s.max_genome_score_col[s.column[i]]) {
+                net.add(s.row[i], s.column[i], sc);
+                net.add(s.column[i], s.row[i], sc);
+                should_add[i] = 1;
+                const int sg = s.second_seq_genome[i];
+                if ((double) sc < 1.0 && sc > inter_max[sg]) inter_max[sg] = sc;
+            }
+        }
+        std::vector<float> thr(n, std::numeric_limits<float>::infinity());   // :146-155
+        for (uint32_t i = 0; i < z; i++)
+            if (should_add[i]) thr[s.row[i]] = std::min(thr[s.row[i]], inter_max[s.second_seq_genome[i]]);
+        for (uint32_t i = 0; i < z; i++) {                                    // :164-176
+            if (s.row[i] < s.column[i] && s.first_seq_genome[i] == s.second_seq_genome[i]) {
+                const float sc = s.scores[i];
+                const int sg = s.second_seq_genome[i];
+                if (sc == s.max_genome_score[(size_t) s.scoresMaxMappings[s.row[i]] * G + sg] &&
+                    sc == s.max_genome_score[(size_t) s.scoresMaxMappings[s.column[i]] * G + sg] && sc >= thr[s.row[i]])
+                    net.add(s.row[i], s.column[i], sc);
+            }
+        }
+        pdl_free_scores(&s);
+    }
+    pdl_destroy(ctx);
+
+    // ---- PangeneNet.saveToFile(file, false) ---------------------------------------------------------------
+    size_t cap = 16;
+    while ((double) net.keys.size() > 0.75 * (double) cap) cap *= 2;
+    std::vector<size_t> order(net.keys.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = i;
+    auto bucket = [&](int32_t key) { const uint32_t h = (uint32_t) key; return (size_t) ((h ^ (h >> 16)) & (uint32_t) (cap - 1)); };
+    std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return bucket(net.keys[x]) < bucket(net.keys[y]); });
+    printf("----------\nwriting into %s\n", output.c_str());
+    FILE *f = fopen(output.c_str(), "w");
+    if (!f) { perror(output.c_str()); return 0; }
+    for (size_t oi : order) {
+        const int32_t src = net.keys[oi];
+        for (const auto &e : net.edges[oi])
+            if (src <= e.first) fprintf(f, "%d\t%d\t%s\n", src, e.first, java_double((double) e.second).c_str());
+    }
+    fclose(f);
+    return 0;
+}

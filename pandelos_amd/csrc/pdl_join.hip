@@ -1,24 +1,28 @@
 // pdl_join.hip — the scoring stage on the device: computeScores (ig/native/library.cpp:409-527) for
 // every gene (row) of every genome of the shard in one pass.
 //
-//   K-join      k_join_lds   sparse all-vs-all multiset-Jaccard join of one row against the dictionary,
-//                            accumulators in an LDS hash table (the reference's dense N-length arrays +
-//                            colour stamps, library.cpp:421-426,467-477), fused finalize
-//                            (library.cpp:493-517) and per-(row, genome) / per-column maxima
-//   K-join-hbm  k_join_hbm   same row program with direct-addressed tables in HBM, for the rows whose
-//                            candidate set does not fit the LDS table
-//   K-order     k_order_rows puts every row's cells in the reference's emission order
+//   K-join      k_join_lds<HT, T, FILTER>   sparse all-vs-all multiset-Jaccard join of one row against the
+//                            dictionary, accumulators in an LDS hash table (the reference's dense N-length arrays
+//                            + colour stamps, library.cpp:421-426,467-477), fused finalize (library.cpp:493-517)
+//                            and per-(row, genome) / per-column maxima.  Tier 1 = small table behind a
+//                            "seen twice" bitmap filter (several rows per CU), tier 2 = 8192-slot table
+//   K-join-hbm  k_join_hbm   tier 3: same row program with direct-addressed tables in HBM
+//   K-order     k_mirror_refs, k_order_rows   every row's cells in the reference's emission order
 //                            (first-touch order, library.cpp:456-482,493 — SURVEY.md §8a row 9a)
 //
-// Row program (both kernels).  A row gene r owns a list of posting ranges, one per record of r that
-// sits in a rank-group of >= 2 records: {group start, group length, own count}.  For every posting
+// Row program (all tiers).  A row gene r owns a list of posting ranges, one per record of r that sits in a
+// rank-group of >= 2 records: {first posting, postings, own count, group size}.  For every posting
 // {c, cnt_c} of every range with own count cnt_r (library.cpp:461-479):
 //       inter[c] += min(cnt_c, cnt_r);  perc_cnt[c] += cnt_r;  tr_cnt[c] += cnt_c
-// The three sums are packed in one 64-bit word (21 bits each: every sum is bounded by twice the
-// k-mer count of a gene, and genes with >= 2^20 k-mers are refused up front), so one lookup is one
-// LDS read + one 64-bit LDS atomic add.  `first` keeps the smallest group start that touched c:
-// the reference emits a row's cells by (column chunk of 2048, first range that touched the column,
-// column), and group starts are monotone in the row's range order.
+// The three sums are packed in one 64-bit word (21 bits each: every sum is bounded by twice the k-mer count
+// of a gene, and genes with >= 2^20 k-mers are refused up front), so one update is one 64-bit LDS atomic.
+// `first` keeps the smallest group start that touched c: the reference emits a row's cells by (column chunk
+// of 2048, first range that touched the column, column), and group starts are monotone in the row's range order.
+//
+// Mirror mode (whole dataset on one device).  Cell (c, r) holds the sums of cell (r, c) with perc_cnt and
+// tr_cnt swapped, and the reference computes both.  Groups are gene-sorted, so a row's ranges start right
+// after its own record: a row only meets the genes above it, and every staged cell also stands for its
+// transpose, which K-order hands to the column's row.  With a genome shard (multi-GPU) rows keep whole groups.
 #include "pdl_common.h"
 #include "pdl_scan.h"
 
@@ -30,9 +34,6 @@ constexpr int HBM_THREADS = 512;                      // workgroup of the HBM-ta
 constexpr uint32_t EMPTY_KEY = 0xffffffffu;
 constexpr uint64_t FIELD_MASK = (1ull << 21) - 1;
 constexpr uint32_t CELL_CHUNK = 16384;                 // staging cells a workgroup reserves at a time (>= any row's candidates in LDS)
-// LDS-table geometry: 8192 slots x 16 B = 128 KiB (+ lists and the staged ranges = 154 KiB), one
-// 1024-thread workgroup per CU (16 waves).  PDL_JOIN_TABLE_BITS=9 selects a deliberately tiny table
-// (512 slots, 64 threads) so that tests can push small inputs through the HBM-table kernel.
 
 struct JoinArgs {
     const uint2 *post;

@@ -90,3 +90,20 @@ def test_device_pipeline_writes_the_fixture_net(name, tmp_path):
     gs.write_faa(faa)
     assert PH.main(["-i", str(faa), "-k", str(k), "-o", str(net)]) == 0
     assert net.read_text() == (NET / f"{name}.net").read_text()
+
+
+@pytest.mark.gpu
+def test_native_host_binary_writes_the_fixture_net(tmp_path):
+    """pandelos_amd/lib/pangenes: the C++ host over the C ABI (what replaces `java ... Pangenes`, pandelos.sh:73)."""
+    from pandelos_amd import _lib
+    name = "synth_8x300x200_k4_div25"
+    shape, k = CASES[name]
+    gs = make_gene_set(**shape)
+    faa, net = tmp_path / "in.faa", tmp_path / "out.net"
+    gs.write_faa(faa)
+    p = subprocess.run([str(_lib.LIB_DIR / "pangenes"), "-i", str(faa), "-k", str(k), "-o", str(net)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    assert net.read_text() == (NET / f"{name}.net").read_text()
+    assert "Total cost:" in p.stdout
+    bad = subprocess.run([str(_lib.LIB_DIR / "pangenes"), "-i", str(faa)], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 1 and "Error while parsing cli arguments!" in bad.stdout      # Cli.java:83-87

@@ -151,7 +151,7 @@ struct pdl_ctx {
     bool tasks_ready = false;  // task layout uploaded for the current shard
     DevBuf scratch2;
     int cus = 0;
-    uint32_t occ_tier1[3] = {0, 0, 0};
+    uint32_t occ_tier1[5] = {0, 0, 0, 0, 0};
 
     pdl_timings tm{};
     EventPair ev[12];

@@ -129,7 +129,7 @@ constexpr uint32_t BM_WORDS = 2048;                        // 65536-bit "seen on
 template <int HT_BITS_, int T_, bool FILTER>
 struct JoinCfg {
     static constexpr uint32_t HT = 1u << HT_BITS_;
-    static constexpr uint32_t LIMIT = FILTER ? HT - T_ - HT / 8 : HT / 4 * 3;   // more keys than this: next tier
+    static constexpr uint32_t LIMIT = HT - T_ - HT / 8;    // more keys than this: next tier
     static constexpr uint32_t TOUCH_CAP = LIMIT + T_;      // < HT: the probe loop always finds a free slot
     static constexpr uint32_t RPT = FILTER ? 2 : 1;        // ranges staged per thread and batch
     static constexpr uint32_t RB = RPT * T_;
@@ -639,9 +639,10 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_order_rows(OrderArgs a) {
             }
             __syncthreads();
             if (live) {
-                for (uint32_t j = 0; j < tn; j++) {
+                for (uint32_t j = 0; j < tn; j++) {          // broadcast reads; the column only breaks (rare) ties
                     const unsigned long long hj = s_hi[j];
-                    rank += (hj < hi) || (hj == hi && s_col[j] < col);
+                    if (hj < hi) rank++;
+                    else if (hj == hi) rank += s_col[j] < col;
                 }
             }
         }
@@ -802,7 +803,7 @@ void pdl_run_score_all(pdl_ctx *c) {
     // PDL_JOIN_TIER1 = 0 | 9 | 10 | 11 picks the tier-1 table (0: skip tier 1); PDL_JOIN_TABLE_BITS=9 swaps
     // tier 2 for a tiny table so that tests can reach tier 3 with small inputs.
     int tier1 = G <= 320 ? 10 : 11;     // keys per row ~ homologs (about one per genome) + repeated/colliding noise
-    if (const char *e = getenv("PDL_JOIN_TIER1")) { const int v = atoi(e); if (v == 0 || (v >= 9 && v <= 11)) tier1 = v; }
+    if (const char *e = getenv("PDL_JOIN_TIER1")) { const int v = atoi(e); if (v == 0 || (v >= 9 && v <= 11) || v == 20 || v == 21) tier1 = v; }
     bool tiny_tier2 = false;
     if (const char *e = getenv("PDL_JOIN_TABLE_BITS")) tiny_tier2 = atoi(e) == 9;
     auto occupancy = [&](const void *fn, int threads) {
@@ -810,11 +811,15 @@ void pdl_run_score_all(pdl_ctx *c) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, threads, 0) != hipSuccess || nb < 1) nb = 1;
         return (uint32_t) nb;
     };
+    // (20 / 21: 1024 / 2048-slot tables WITHOUT the filter, one pass)
     const void *fn1 = tier1 == 9 ? (const void *) k_join_lds<9, 128, true>
-                    : tier1 == 10 ? (const void *) k_join_lds<10, 256, true> : (const void *) k_join_lds<11, 256, true>;
+                    : tier1 == 10 ? (const void *) k_join_lds<10, 256, true>
+                    : tier1 == 11 ? (const void *) k_join_lds<11, 256, true>
+                    : tier1 == 20 ? (const void *) k_join_lds<10, 256, false> : (const void *) k_join_lds<11, 256, false>;
     const int t1_threads = tier1 == 9 ? 128 : 256;
-    if (tier1 && c->occ_tier1[tier1 - 9] == 0) c->occ_tier1[tier1 - 9] = occupancy(fn1, t1_threads);
-    const uint32_t grid1 = tier1 ? std::min<uint32_t>(n_rows, (uint32_t) cus * c->occ_tier1[tier1 - 9]) : 0;
+    const int occ_slot = tier1 >= 20 ? tier1 - 20 + 3 : tier1 - 9;
+    if (tier1 && c->occ_tier1[occ_slot] == 0) c->occ_tier1[occ_slot] = occupancy(fn1, t1_threads);
+    const uint32_t grid1 = tier1 ? std::min<uint32_t>(n_rows, (uint32_t) cus * c->occ_tier1[occ_slot]) : 0;
     const uint32_t grid2 = std::min<uint32_t>(n_rows, (uint32_t) cus * (tiny_tier2 ? 4 : 1));
     const uint32_t grid3 = (uint32_t) std::min<int>(cus, 64);
     const size_t hbm_bytes = (size_t) grid3 * N * (sizeof(uint64_t) + 3 * sizeof(uint32_t));
@@ -873,6 +878,8 @@ void pdl_run_score_all(pdl_ctx *c) {
         if (tier1 == 9) hipLaunchKernelGGL((k_join_lds<9, 128, true>), dim3(grid1), dim3(128), 0, st, a);
         else if (tier1 == 10) hipLaunchKernelGGL((k_join_lds<10, 256, true>), dim3(grid1), dim3(256), 0, st, a);
         else if (tier1 == 11) hipLaunchKernelGGL((k_join_lds<11, 256, true>), dim3(grid1), dim3(256), 0, st, a);
+        else if (tier1 == 20) hipLaunchKernelGGL((k_join_lds<10, 256, false>), dim3(grid1), dim3(256), 0, st, a);
+        else if (tier1 == 21) hipLaunchKernelGGL((k_join_lds<11, 256, false>), dim3(grid1), dim3(256), 0, st, a);
         // tier 2 over list A (or over everything when tier 1 is off)
         if (tier1) {
             hipLaunchKernelGGL(k_row_desc_list, dim3((n_rows + 255) / 256), dim3(256), 0, st, list_a, ctr32 + 1, c->task_rows.as<uint32_t>(),

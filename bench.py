@@ -178,7 +178,7 @@ def main():
     # profiles/*_pmc_traffic_join.json).  null when no profile of this workload/sharding is on file.
     traffic = None
     if n_gpus == 1 and not args.faa:
-        for pf in sorted((ROOT / "profiles").glob("*_pmc_traffic_join.json"), reverse=True):
+        for pf in sorted((ROOT / "profiles").glob("r*b_pmc_traffic_join.json"), reverse=True):
             try:
                 prof = json.loads(pf.read_text())
                 if prof.get("workload") == args.config:

@@ -190,3 +190,23 @@ def test_shard_set_before_preprocess_builds_only_its_rows():
         with pytest.raises(_lib.PdlError):
             nat.set_genome_shard([0, 1, 2, 3, 4])       # wider than what the dictionary was built for
     assert total == int(fx["total_cost"])
+
+
+def test_last_record_fold_moves_through_a_large_group():
+    """The globally last record (a singleton of the largest rank) is folded into the preceding rank-group and re-sorted
+    by gene (library.cpp:300-315).  Here that group has 3000 members and the folded record belongs to gene 0, so the
+    device's insertion shift walks several 1024-element chunks."""
+    from oracle import binding as ob
+    genes = [b"YYAA"] + [b"AAYA"] * 3000 + [b"AAAA", b"AYAA"]
+    # ranks (k=2, A<Y): AA < AY < YA < YY; YY only in gene 0 -> last record, folded into the YA group (genes 1..3000, 3002)
+    residues = np.frombuffer(b"".join(genes), np.uint8)
+    offsets = np.arange(len(genes) + 1, dtype=np.uint64) * 4
+    genome_of = (np.arange(len(genes)) % 7).astype(np.uint32)
+    nat = _native(residues, offsets, genome_of, 2)
+    ora = ob.Oracle(residues, offsets, genome_of, 2)
+    assert nat.cost.total_cost == ora.total_cost
+    ranks, seqs, counts = nat.dictionary()
+    d = ora.dictionary()
+    assert np.array_equal(ranks, d["rank"]) and np.array_equal(seqs, d["seq"]) and np.array_equal(counts, d["count"])
+    for g in range(7):
+        H.assert_scores_equal(nat.generate_scores_part(g).as_dict(), ora.scores(g), f"genome {g}")

@@ -93,13 +93,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
+    # PDL_BENCH_BACKEND=gloo + PDL_BENCH_ONE_DEVICE=1 rehearse the N > 1 flow on a one-GPU box (every rank on cuda:0,
+    # collectives on CPU tensors); the driver's runs use RCCL ("nccl"), one rank per GPU.
+    backend = os.environ.get("PDL_BENCH_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("PDL_BENCH_ONE_DEVICE") == "1" else local_rank
+    dev = torch.device("cuda", dev_index)
+    torch.cuda.set_device(dev)
     if distributed:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     n_gpus = world if distributed else 1
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+    coll_dev = dev if backend == "nccl" else None      # where the scalar collectives live
 
     # ---- workload -----------------------------------------------------------------------------------
     if args.faa:
@@ -133,7 +140,7 @@ def main():
     nat = PangeneNative.open(stream=stream)
     if n_gpus > 1:
         shard = D.shard_for_rank(gs.offsets, gs.genome_of, n_gpus, rank)
-        D.gather_genome_owner(shard, n_genomes, device=dev)      # the shards must partition the genomes
+        D.gather_genome_owner(shard, n_genomes, device=coll_dev)      # the shards must partition the genomes
         nat.set_genome_shard(shard)
 
     def one_step():
@@ -159,7 +166,7 @@ def main():
         score_ms.append(tm["score_total_ms"])
     sync()
     elapsed = time.perf_counter() - t0
-    elapsed = D.all_reduce_max(elapsed, device=dev)
+    elapsed = D.all_reduce_max(elapsed, device=coll_dev)
     sec_per_step = elapsed / max(args.steps, 1)
 
     cost = nat.cost
@@ -169,7 +176,7 @@ def main():
     join_bytes = 8.0 * p_l + 20.0 * z_l + 8.0 * rows_l * n_genomes
     join_s = (sum(join_ms) / len(join_ms)) / 1e3 if join_ms else 0.0
     achieved = join_bytes / join_s / 1e9 if join_s > 0 else 0.0
-    z_total, p_total = D.all_reduce_sum([float(z_l), float(cost.total_cost)], device=dev)
+    z_total, p_total = D.all_reduce_sum([float(z_l), float(cost.total_cost)], device=coll_dev)
     bytes_alg_total = (cost.residues + 16.0 * cost.kmer_occurrences + 16.0 * cost.dictionary_records +
                        8.0 * p_total + 20.0 * z_total + 8.0 * n_genes * n_genomes)
 

@@ -45,6 +45,8 @@ pdl_ctx *pdl_create(const pdl_config *cfg) {
         c->flags = cfg ? cfg->flags : 0;
         if (cfg && cfg->stream) { c->stream = (hipStream_t) cfg->stream; c->own_stream = false; }
         else { PDL_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+        if (hipHostMalloc((void **) &c->pin, 1 << 20, hipHostMallocDefault) == hipSuccess) c->pin_bytes = 1 << 20;
+        else { c->pin = nullptr; (void) hipGetLastError(); }
         return c;
     } catch (const pdl_error &e) {
         g_create_error = e.msg;
@@ -59,6 +61,7 @@ void pdl_destroy(pdl_ctx *c) {
     (void) hipStreamSynchronize(c->stream);
     for (auto &e : c->ev) { if (e.a) (void) hipEventDestroy(e.a); if (e.b) (void) hipEventDestroy(e.b); }
     if (c->own_stream && c->stream) (void) hipStreamDestroy(c->stream);
+    if (c->pin) (void) hipHostFree(c->pin);
     delete c;
 }
 

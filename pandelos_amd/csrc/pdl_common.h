@@ -7,7 +7,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <mutex>
+#include <cstdlib>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/pandelos_amd.h"
@@ -155,6 +157,31 @@ struct pdl_ctx {
 
     pdl_timings tm{};
     EventPair ev[12];
+    uint8_t *pin = nullptr;       // pinned host scratch for the small device->host reads (true async DMA, no staging copy)
+    size_t pin_bytes = 0;
+};
+
+// Small device->host reads through the pinned scratch: queue with add(), one sync(), then read the returned pointers.
+struct PinRead {
+    pdl_ctx *c;
+    size_t used = 0;
+    std::vector<std::pair<void *, std::pair<const void *, size_t>>> spill;   // reads that did not fit: done pageable
+    explicit PinRead(pdl_ctx *ctx) : c(ctx) {}
+    template <class T> const T *add(const void *d_src, size_t count) {
+        const size_t bytes = count * sizeof(T);
+        const size_t at = (used + 15) & ~(size_t) 15;
+        if (c->pin && at + bytes <= c->pin_bytes) {
+            used = at + bytes;
+            PDL_HIP(hipMemcpyAsync(c->pin + at, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+            return reinterpret_cast<const T *>(c->pin + at);
+        }
+        void *h = malloc(bytes ? bytes : 1);
+        spill.push_back({h, {d_src, bytes}});
+        PDL_HIP(hipMemcpyAsync(h, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+        return reinterpret_cast<const T *>(h);
+    }
+    void sync() { PDL_HIP(hipStreamSynchronize(c->stream)); }
+    ~PinRead() { for (auto &e : spill) free(e.first); }
 };
 
 // stage entry points (pdl_dict.hip / pdl_join.hip)

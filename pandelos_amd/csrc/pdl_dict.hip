@@ -458,8 +458,7 @@ static void dictionary_pipeline(pdl_ctx *c, bool only_complexity) {
     c->recpos.alloc((M + 1) * sizeof(uint32_t));
     scan_and_apply(c, M, RecHead<KeyT>{skeys, svals}, RecScatter{c->recpos.as<uint32_t>()}, d_scal + 0);
     uint64_t U = 0;
-    PDL_HIP(hipMemcpyAsync(&U, d_scal + 0, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    PDL_HIP(hipStreamSynchronize(st));
+    { PinRead rd(c); const uint64_t *pu = rd.add<uint64_t>(d_scal + 0, 1); rd.sync(); U = *pu; }
     c->U = U;
     const uint32_t Uu = (uint32_t) U;
     const uint32_t ublocks = (Uu + 255) / 256;
@@ -513,8 +512,7 @@ static void dictionary_pipeline(pdl_ctx *c, bool only_complexity) {
                                      upper_only, c->cost.as<unsigned long long>()}, d_scal + 2);
         c->upper_only = upper_only != 0;
         uint64_t Us = 0;
-        PDL_HIP(hipMemcpyAsync(&Us, d_scal + 2, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-        PDL_HIP(hipStreamSynchronize(st));
+        { PinRead rd(c); const uint64_t *pu = rd.add<uint64_t>(d_scal + 2, 1); rd.sync(); Us = *pu; }
         const uint32_t seq_bits = std::max<uint32_t>(1, bit_length64(c->N ? c->N - 1 : 0));
         pdl_sort_pairs<uint32_t>(c, k2a, k2b, v2a, v2b, Us, seq_bits);     // sorted pairs now in (k2b, v2b)
         ev_end(c, EV_SORT2);
@@ -539,11 +537,15 @@ static void dictionary_pipeline(pdl_ctx *c, bool only_complexity) {
                        reinterpret_cast<unsigned long long *>(d_scal + 4), reinterpret_cast<unsigned long long *>(d_scal + 7),
                        reinterpret_cast<unsigned long long *>(d_scal + 8));
 
-    c->h_genome_cost.assign(c->G, 0);
-    PDL_HIP(hipMemcpyAsync(c->h_genome_cost.data(), c->genome_cost.p, (size_t) c->G * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     uint64_t tail[9] = {0};
-    PDL_HIP(hipMemcpyAsync(tail, d_scal, 9 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    PDL_HIP(hipStreamSynchronize(st));
+    {
+        PinRead rd(c);
+        const uint64_t *pg = rd.add<uint64_t>(c->genome_cost.p, c->G);
+        const uint64_t *pt = rd.add<uint64_t>(d_scal, 9);
+        rd.sync();
+        c->h_genome_cost.assign(pg, pg + c->G);
+        memcpy(tail, pt, sizeof(tail));
+    }
     c->Ushared = tail[2];
     // every record outside the shared groups is a group of its own: shared groups = all groups - singletons
     c->NG = c->dict_shard.empty() ? tail[1] - (c->U - c->Ushared) : 0;   // (not counted when only a shard's lists are built)
@@ -576,10 +578,15 @@ void pdl_run_preprocess(pdl_ctx *c, int kvalue, bool only_complexity) {
     PDL_HIP(hipMemcpyAsync(c->kmer_off.as<uint64_t>() + c->N, d_scal + 5, sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
     uint64_t counters[256];
     uint64_t M = 0;
-    PDL_HIP(hipMemcpyAsync(counters, c->hist.p, sizeof(counters), hipMemcpyDeviceToHost, st));
-    PDL_HIP(hipMemcpyAsync(&M, d_scal + 5, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    ev_end(c, EV_HIST);
-    PDL_HIP(hipStreamSynchronize(st));
+    {
+        PinRead rd(c);
+        const uint64_t *pc = rd.add<uint64_t>(c->hist.p, 256);
+        const uint64_t *pm = rd.add<uint64_t>(d_scal + 5, 1);
+        ev_end(c, EV_HIST);
+        rd.sync();
+        memcpy(counters, pc, sizeof(counters));
+        M = *pm;
+    }
 
     rank_init_host(c->rp, counters, kvalue);
     c->M = M;

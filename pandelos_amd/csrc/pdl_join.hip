@@ -934,11 +934,17 @@ void pdl_run_score_all(pdl_ctx *c) {
         c->h_fin.resize(S + 1);
         uint32_t h_ctr[8];
         uint64_t zsum = 0;
-        PDL_HIP(hipMemcpyAsync(c->h_fin.data(), d_out, (size_t) (S + 1) * 4, hipMemcpyDeviceToHost, st));
-        PDL_HIP(hipMemcpyAsync(h_ctr, c->join_ctr.p, sizeof(h_ctr), hipMemcpyDeviceToHost, st));
-        PDL_HIP(hipMemcpyAsync(&zsum, d_scal + 6, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-        ev_end(c, EV_SCORE_TOTAL);
-        PDL_HIP(hipStreamSynchronize(st));
+        {
+            PinRead rd(c);
+            const uint32_t *pf = rd.add<uint32_t>(d_out, S + 1);
+            const uint32_t *pc = rd.add<uint32_t>(c->join_ctr.p, 8);
+            const uint64_t *pz = rd.add<uint64_t>(d_scal + 6, 1);
+            ev_end(c, EV_SCORE_TOTAL);
+            rd.sync();
+            memcpy(c->h_fin.data(), pf, (size_t) (S + 1) * 4);
+            memcpy(h_ctr, pc, sizeof(h_ctr));
+            zsum = *pz;
+        }
         c->glb_clean = true;
         c->tm.overflow_rows = h_ctr[3];
         c->tm.tier2_rows = tier1 ? h_ctr[1] : n_rows;

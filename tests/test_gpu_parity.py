@@ -210,3 +210,47 @@ def test_last_record_fold_moves_through_a_large_group():
     assert np.array_equal(ranks, d["rank"]) and np.array_equal(seqs, d["seq"]) and np.array_equal(counts, d["count"])
     for g in range(7):
         H.assert_scores_equal(nat.generate_scores_part(g).as_dict(), ora.scores(g), f"genome {g}")
+
+
+def _flat(genes, genome_ids):
+    residues = np.frombuffer(b"".join(genes), np.uint8)
+    offsets = np.zeros(len(genes) + 1, np.uint64)
+    np.cumsum([len(g) for g in genes], out=offsets[1:])
+    return residues, offsets, np.asarray(genome_ids, np.uint32)
+
+
+@pytest.mark.parametrize("case", ["single_gene", "single_genome", "identical_genes", "bytes_above_127", "k1",
+                                  "one_very_long_gene", "empty_genes_between"])
+def test_edge_cases_match_the_oracle(case):
+    from oracle import binding as ob
+    rng = np.random.default_rng(9)
+    aa = b"ACDEFGHIKLMNPQRSTVWY"
+    rnd = lambda n: bytes(aa[i] for i in rng.integers(0, 20, n))
+    if case == "single_gene":
+        genes, gid, k = [rnd(50)], [0], 3
+    elif case == "single_genome":                      # only intra-genome cells
+        base = rnd(120)
+        genes, gid, k = [base, base[:60] + rnd(60), rnd(100), base[30:] + rnd(10)], [0, 0, 0, 0], 3
+    elif case == "identical_genes":                    # scores of exactly 1.0 in several genomes
+        base = rnd(90)
+        genes, gid, k = [base, base, base, rnd(80), base, rnd(70)], [0, 1, 2, 0, 0, 1], 4
+    elif case == "bytes_above_127":                    # Latin-1 residues: rank table covers all 256 byte values
+        genes = [bytes(rng.integers(128, 256, 80).astype(np.uint8)) for _ in range(6)]
+        genes[3] = genes[0][:50] + genes[3][50:]
+        gid, k = [0, 0, 1, 1, 2, 2], 2
+    elif case == "k1":
+        genes, gid, k = [rnd(30) for _ in range(8)], [0, 1, 2, 3, 0, 1, 2, 3], 1
+    elif case == "one_very_long_gene":                 # 60 000 residues: tens of thousands of candidates -> big LDS / HBM tiers
+        long_gene = rnd(60000)
+        genes = [long_gene] + [long_gene[i * 100:i * 100 + 150] for i in range(300)] + [rnd(200) for _ in range(50)]
+        gid, k = [i % 5 for i in range(len(genes))], 3
+    else:                                               # genes shorter than k (even empty) in the middle of the stream
+        genes, gid, k = [rnd(40), b"", b"AC", rnd(40), b"A", rnd(45), b""], [0, 0, 1, 1, 2, 2, 2], 3
+        genes[3] = genes[0][:30] + genes[3][30:]
+    res, off, gen = _flat(genes, gid)
+    nat = _native(res, off, gen, k)
+    ora = ob.Oracle(res, off, gen, k)
+    assert nat.cost.total_cost == ora.total_cost
+    assert nat.cost.genomes == ora.genomes
+    for g in range(ora.genomes):
+        H.assert_scores_equal(nat.generate_scores_part(g).as_dict(), ora.scores(g), f"{case} genome {g}")

@@ -82,6 +82,14 @@ __device__ __forceinline__ uint32_t min_numerator(float threshold, float denom) 
 }
 
 // finalize one candidate (library.cpp:494-502); returns score (0 when not emitted)
+__device__ __forceinline__ float finalize_counts(int inter, int pc, int tc, uint32_t my_kcnt, uint32_t other_kcnt, float threshold,
+                                                 float &perc, float &tr_perc) {
+    const int union_size = (int) my_kcnt + (int) other_kcnt - inter;
+    perc = (float) pc / (float) (int) my_kcnt;
+    tr_perc = (float) tc / (float) (int) other_kcnt;
+    const bool score_valid = perc >= threshold || tr_perc >= threshold;
+    return (float) inter / (float) union_size * (score_valid ? 1.0f : 0.0f);
+}
 __device__ __forceinline__ float finalize_cell(unsigned long long acc, uint32_t my_kcnt, uint32_t other_kcnt, float threshold,
                                                float &perc, float &tr_perc) {
     const int inter = (int) (acc & FIELD_MASK);
@@ -469,13 +477,24 @@ __device__ __forceinline__ unsigned long long ld_agent(const unsigned long long 
 __device__ __forceinline__ void st_agent(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// WIDE = true keeps the three sums in separate 32-bit counters (the reference's int arrays, library.cpp:421-423) instead of
+// the packed 21-bit fields: the only path for datasets with a gene of >= 2^20 k-mers, where every row is sent here.
+template <bool WIDE>
 __global__ __launch_bounds__(HBM_THREADS) void k_join_hbm(JoinArgs a) {
     constexpr int JOIN_THREADS = HBM_THREADS;
     __shared__ uint32_t s_ntouched, s_nemit, s_work, s_batch_end;
     __shared__ unsigned long long s_base;
     const uint32_t tid = threadIdx.x;
-    unsigned long long *t_acc = a.hbm_acc + (size_t) blockIdx.x * a.N;
+    unsigned long long *t_acc = a.hbm_acc + (size_t) blockIdx.x * (WIDE ? 2 : 1) * a.N;      // WIDE: u32 [3][N] in the same bytes (+ N spare)
+    uint32_t *t_w = reinterpret_cast<uint32_t *>(t_acc);
     uint32_t *t_first = a.hbm_u32 + (size_t) blockIdx.x * 3 * a.N;
+    auto read_cell = [&](uint32_t c, uint32_t my_kcnt, float threshold, float &perc, float &tr) -> float {
+        if constexpr (WIDE)
+            return finalize_counts((int) ld_agent(&t_w[c]), (int) ld_agent(&t_w[a.N + c]), (int) ld_agent(&t_w[2 * (size_t) a.N + c]),
+                                   my_kcnt, a.kseq_len[c], threshold, perc, tr);
+        else
+            return finalize_cell(ld_agent(&t_acc[c]), my_kcnt, a.kseq_len[c], threshold, perc, tr);
+    };
     uint32_t *t_touched = t_first + a.N;
     uint32_t *t_emit = t_touched + a.N;
     if (tid == 0) { s_ntouched = 0; s_nemit = 0; s_work = 0xffffffffu; s_batch_end = 0; }
@@ -509,8 +528,14 @@ __global__ __launch_bounds__(HBM_THREADS) void k_join_hbm(JoinArgs a) {
                         if (idx < a.N) t_touched[idx] = c; else atomicAdd(a.error_count, 1u);
                     }
                 }
-                const unsigned long long add = (unsigned long long) min(po.y, rg.z) | ((unsigned long long) rg.z << 21) | ((unsigned long long) po.y << 42);
-                atomicAdd(&t_acc[c], add);
+                if constexpr (WIDE) {
+                    atomicAdd(&t_w[c], min(po.y, rg.z));
+                    atomicAdd(&t_w[a.N + c], rg.z);
+                    atomicAdd(&t_w[2 * (size_t) a.N + c], po.y);
+                } else {
+                    const unsigned long long add = (unsigned long long) min(po.y, rg.z) | ((unsigned long long) rg.z << 21) | ((unsigned long long) po.y << 42);
+                    atomicAdd(&t_acc[c], add);
+                }
             }
         }
         __threadfence();      // the touched list was written with plain stores by other waves of this workgroup
@@ -521,7 +546,7 @@ __global__ __launch_bounds__(HBM_THREADS) void k_join_hbm(JoinArgs a) {
             const uint32_t c = ld_agent(&t_touched[t]);
             if (c == r || c >= a.N) continue;
             float perc, tr;
-            const float score = finalize_cell(ld_agent(&t_acc[c]), my_kcnt, a.kseq_len[c], threshold, perc, tr);
+            const float score = read_cell(c, my_kcnt, threshold, perc, tr);
             if (score > 0.0f) {
                 const uint32_t idx = atomicAdd(&s_nemit, 1u);
                 if (idx < a.N) st_agent(&t_emit[idx], c);
@@ -543,7 +568,7 @@ __global__ __launch_bounds__(HBM_THREADS) void k_join_hbm(JoinArgs a) {
             for (uint32_t i = tid; i < nemit; i += JOIN_THREADS) {
                 const uint32_t c = ld_agent(&t_emit[i]);
                 float perc, tr;
-                const float score = finalize_cell(ld_agent(&t_acc[c]), my_kcnt, a.kseq_len[c], threshold, perc, tr);
+                const float score = read_cell(c, my_kcnt, threshold, perc, tr);
                 const unsigned long long o = base + i;
                 a.st_score[o] = score; a.st_perc[o] = perc; a.st_tr[o] = tr;
                 a.st_col[o] = c; a.st_first[o] = 0xffffffffu - ld_agent(&t_first[c]);
@@ -562,7 +587,11 @@ __global__ __launch_bounds__(HBM_THREADS) void k_join_hbm(JoinArgs a) {
         __syncthreads();
         for (uint32_t t = tid; t < ntouched; t += JOIN_THREADS) {
             const uint32_t c = ld_agent(&t_touched[t]);
-            if (c < a.N) { st_agent(&t_acc[c], 0ull); st_agent(&t_first[c], 0u); }
+            if (c < a.N) {
+                if constexpr (WIDE) { st_agent(&t_w[c], 0u); st_agent(&t_w[a.N + c], 0u); st_agent(&t_w[2 * (size_t) a.N + c], 0u); }
+                else st_agent(&t_acc[c], 0ull);
+                st_agent(&t_first[c], 0u);
+            }
         }
         if (tid == 0) { s_ntouched = 0; s_nemit = 0; }
         __threadfence();      // the zeroing stores must have landed before the next row's atomics
@@ -751,12 +780,15 @@ void pdl_prepare_tasks(pdl_ctx *c) {
 }
 
 __global__ void k_set_u32_from_u64(uint32_t *dst, const uint64_t *src) { *dst = (uint32_t) *src; }
+__global__ void k_iota_u32(uint32_t *dst, uint32_t n) { uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) dst[i] = i; }
 
 void pdl_run_score_all(pdl_ctx *c) {
     hipStream_t st = c->stream;
     const uint32_t N = c->N, G = c->G;
-    if (c->max_kseq >= (1ull << 20))
-        PDL_FAIL(PDL_ERR_UNSUPPORTED, "a gene with %llu k-mers exceeds the 2^20 limit of the packed accumulators", (unsigned long long) c->max_kseq);
+    // the LDS tiers pack the three sums of a cell in 21-bit fields; a gene with >= 2^20 k-mers could overflow them, so
+    // such a dataset is scored entirely by the HBM kernel with 32-bit counters (the reference's ints)
+    const bool wide = c->max_kseq >= (1ull << 20);
+    if (c->max_kseq >= (1ull << 31)) PDL_FAIL(PDL_ERR_UNSUPPORTED, "a gene with %llu k-mers exceeds the reference's int counters", (unsigned long long) c->max_kseq);
     ev_begin(c, EV_SCORE_TOTAL);
     if (!c->tasks_ready) pdl_prepare_tasks(c);
     const uint32_t S = (uint32_t) c->shard.size();
@@ -822,7 +854,7 @@ void pdl_run_score_all(pdl_ctx *c) {
     const uint32_t grid1 = tier1 ? std::min<uint32_t>(n_rows, (uint32_t) cus * c->occ_tier1[occ_slot]) : 0;
     const uint32_t grid2 = std::min<uint32_t>(n_rows, (uint32_t) cus * (tiny_tier2 ? 4 : 1));
     const uint32_t grid3 = (uint32_t) std::min<int>(cus, 64);
-    const size_t hbm_bytes = (size_t) grid3 * N * (sizeof(uint64_t) + 3 * sizeof(uint32_t));
+    const size_t hbm_bytes = (size_t) grid3 * N * ((wide ? 2 : 1) * sizeof(uint64_t) + 3 * sizeof(uint32_t));
     if (c->glb_table.bytes < hbm_bytes) { c->glb_table.alloc(hbm_bytes); c->glb_clean = false; }
     if (!c->glb_clean) {      // k_join_hbm leaves its tables zeroed: one memset per allocation
         PDL_HIP(hipMemsetAsync(c->glb_table.p, 0, hbm_bytes, st));
@@ -871,8 +903,12 @@ void pdl_run_score_all(pdl_ctx *c) {
         a.cell_cursor = reinterpret_cast<unsigned long long *>(ctr32 + 4);
 
         ev_begin(c, EV_JOIN);
+        if (wide) {          // every row straight to tier 3: list B = all task positions
+            hipLaunchKernelGGL(k_iota_u32, dim3((n_rows + 255) / 256), dim3(256), 0, st, list_b, n_rows);
+            PDL_HIP(hipMemcpyAsync(ctr32 + 3, &c->n_task_rows, 4, hipMemcpyHostToDevice, st));
+        }
         // tier 1
-        a.work = nullptr; a.desc = c->row_desc.as<uint4>(); a.n_work = n_rows; a.n_work_ptr = nullptr;
+        a.work = nullptr; a.desc = c->row_desc.as<uint4>(); a.n_work = wide ? 0 : n_rows; a.n_work_ptr = nullptr;
         a.work_cursor = ctr32 + 0; a.overflow_count = ctr32 + 1; a.overflow_rows = list_a;
         a.work_batch = std::max<uint32_t>(1, std::min<uint32_t>(8, n_rows / (std::max<uint32_t>(grid1, 1) * 8)));
         if (tier1 == 9) hipLaunchKernelGGL((k_join_lds<9, 128, true>), dim3(grid1), dim3(128), 0, st, a);
@@ -888,17 +924,19 @@ void pdl_run_score_all(pdl_ctx *c) {
         }
         a.work_cursor = ctr32 + 2; a.overflow_count = ctr32 + 3; a.overflow_rows = list_b;
         a.work_batch = tier1 ? 1 : std::max<uint32_t>(1, std::min<uint32_t>(8, n_rows / (grid2 * 8)));
+        if (wide && !tier1) a.n_work = 0;
         if (tiny_tier2) hipLaunchKernelGGL((k_join_lds<9, 64, false>), dim3(grid2), dim3(64), 0, st, a);
         else hipLaunchKernelGGL((k_join_lds<13, 1024, false>), dim3(grid2), dim3(1024), 0, st, a);
         PDL_HIP(hipGetLastError());
         ev_end(c, EV_JOIN);
         // tier 3 over list B
         a.hbm_acc = c->glb_table.as<unsigned long long>();
-        a.hbm_u32 = reinterpret_cast<uint32_t *>(a.hbm_acc + (size_t) grid3 * N);
+        a.hbm_u32 = reinterpret_cast<uint32_t *>(a.hbm_acc + (size_t) grid3 * N * (wide ? 2 : 1));
         a.work = list_b; a.n_work = 0; a.n_work_ptr = ctr32 + 3; a.work_cursor = ctr32 + 7; a.work_batch = 1;
         ev_begin(c, EV_JOIN_OVF);
         c->glb_clean = false;
-        hipLaunchKernelGGL(k_join_hbm, dim3(grid3), dim3(HBM_THREADS), 0, st, a);
+        if (wide) hipLaunchKernelGGL(k_join_hbm<true>, dim3(grid3), dim3(HBM_THREADS), 0, st, a);
+        else hipLaunchKernelGGL(k_join_hbm<false>, dim3(grid3), dim3(HBM_THREADS), 0, st, a);
         PDL_HIP(hipGetLastError());
         ev_end(c, EV_JOIN_OVF);
         c->tm.join_launches += 3;

@@ -254,3 +254,20 @@ def test_edge_cases_match_the_oracle(case):
     assert nat.cost.genomes == ora.genomes
     for g in range(ora.genomes):
         H.assert_scores_equal(nat.generate_scores_part(g).as_dict(), ora.scores(g), f"{case} genome {g}")
+
+
+def test_gene_with_over_a_million_kmers_uses_wide_counters():
+    """>= 2^20 k-mers in one gene: the packed 21-bit accumulators could overflow, every row goes to the HBM kernel with
+    32-bit counters (the reference's int arrays, library.cpp:421-423)."""
+    from oracle import binding as ob
+    rng = np.random.default_rng(12)
+    aa = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
+    giant = aa[rng.integers(0, 20, (1 << 20) + 5000)].tobytes()
+    genes = [giant] + [giant[i * 9973:i * 9973 + 400] for i in range(40)] + [aa[rng.integers(0, 20, 300)].tobytes() for _ in range(20)]
+    res, off, gen = _flat(genes, [i % 4 for i in range(len(genes))])
+    nat = _native(res, off, gen, 4)
+    ora = ob.Oracle(res, off, gen, 4)
+    assert nat.cost.total_cost == ora.total_cost
+    for g in range(4):
+        H.assert_scores_equal(nat.generate_scores_part(g).as_dict(), ora.scores(g), f"genome {g}")
+    assert nat.timings()["overflow_rows"] == len(genes)

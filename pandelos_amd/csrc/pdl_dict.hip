@@ -6,7 +6,7 @@
 //   K-len     k_kseq_len          kseq_lengths + k-mer stream offsets        library.cpp:250-262
 //   K-rank    k_rank / k_rank_hash   per-gene k-mer ranks                    library.cpp:75-86,134-150
 //   K-sort    pdl_sort_pairs      stable LSD radix sort by rank              library.cpp:172-187,270-278
-//   K-rle     RecHead/RecScatter, k_build_records   dedup -> (rank,gene,count)   library.cpp:280-287
+//   K-rle     RecHead/RecScatter scan (records built in the apply)   dedup -> (rank,gene,count)   library.cpp:280-287
 //   K-groups  GroupHead scan, k_group_offsets, k_record_costs (+ the last-record fold)  library.cpp:297-335
 //   K-ranges  SharedScatter compaction, sort by gene, k_gather_ranges, k_seq_offsets, k_row_costs   library.cpp:312-327
 //   K-cost    k_genome_cost       per-genome and total lookups               library.cpp:337-350,535-538
@@ -211,34 +211,30 @@ template <class KeyT> struct RecHead {
         return (q == 0 || keys[q] != keys[q - 1] || vals[q] != vals[q - 1]) ? 1u : 0u;
     }
 };
-struct RecScatter {
-    uint32_t *recpos;
-    __device__ void operator()(uint64_t q, uint32_t f, uint32_t prefix) const { if (f) recpos[prefix] = (uint32_t) q; }
+// The apply side also builds the record: post[u] = {gene, run length}, ghead[u] = 1 when record u opens a rank-group
+// (its rank differs from the element just before it, which belongs to the previous record).  Runs are short (a k-mer
+// repeated inside one gene), so the head walks its own run.
+template <class KeyT> struct RecScatter {
+    const KeyT *keys; const uint32_t *vals; uint64_t m;
+    uint32_t *recpos; uint2 *post; uint8_t *ghead;
+    __device__ void operator()(uint64_t q, uint32_t f, uint32_t prefix) const {
+        if (!f) return;
+        const KeyT key = keys[q];
+        const uint32_t val = vals[q];
+        uint64_t j = q + 1;
+        while (j < m && keys[j] == key && vals[j] == val) j++;
+        recpos[prefix] = (uint32_t) q;
+        post[prefix] = make_uint2(val, (uint32_t) (j - q));
+        ghead[prefix] = (q == 0 || keys[q - 1] != key) ? 1 : 0;
+    }
 };
 
-// post[u] = {gene, count}; ghead[u] = 1 when record u opens a rank-group.  The reference's scan
-// (library.cpp:300-306) closes the current group at the LAST record with end = i + 1 whatever its
-// rank, i.e. the last record never opens a group: when it is the only record of the largest rank
-// it is folded into the preceding group.  (The reference then re-sorts that group by gene, :312-315;
-// nothing downstream of this dictionary depends on the order inside a group, so no re-sort here.)
-template <class KeyT>
-__global__ __launch_bounds__(256) void k_build_records(const KeyT *__restrict__ keys, const uint32_t *__restrict__ vals,
-                                                       const uint32_t *__restrict__ recpos, uint64_t m, uint32_t u_count,
-                                                       uint2 *__restrict__ post, uint8_t *__restrict__ ghead) {
-    const uint32_t u = blockIdx.x * 256 + threadIdx.x;
-    if (u >= u_count) return;
-    const uint32_t q = recpos[u];
-    const uint32_t qn = (u + 1 < u_count) ? recpos[u + 1] : (uint32_t) m;
-    post[u] = make_uint2(vals[q], qn - q);
-    uint8_t h = 1;
-    if (u > 0) h = keys[q] != keys[recpos[u - 1]];
-    if (u_count >= 2 && u == u_count - 1) h = 0;
-    ghead[u] = h;
-}
-
+// The reference's scan (library.cpp:300-306) closes the current group at the LAST record with end = i + 1 whatever
+// its rank, i.e. the last record never opens a group: when it is the only record of the largest rank it is folded
+// into the preceding group (and moved to its gene-order place by k_fold_last_record).
 struct GroupHeadFlag {
-    const uint8_t *ghead;
-    __device__ uint32_t operator()(uint64_t u) const { return ghead[u]; }
+    const uint8_t *ghead; uint64_t u_count;
+    __device__ uint32_t operator()(uint64_t u) const { return (u_count >= 2 && u == u_count - 1) ? 0u : ghead[u]; }
 };
 struct GroupScatter {
     uint32_t *gid; uint32_t *goff;
@@ -456,21 +452,19 @@ static void dictionary_pipeline(pdl_ctx *c, bool only_complexity) {
     // K-rle
     ev_begin(c, EV_DICT);
     c->recpos.alloc((M + 1) * sizeof(uint32_t));
-    scan_and_apply(c, M, RecHead<KeyT>{skeys, svals}, RecScatter{c->recpos.as<uint32_t>()}, d_scal + 0);
+    c->post.alloc(M * sizeof(uint2));                           // U <= M records (sized before U is known)
+    uint8_t *ghead = reinterpret_cast<uint8_t *>(c->keys_a.p);   // keys_a is free after the sort (>= M bytes)
+    scan_and_apply(c, M, RecHead<KeyT>{skeys, svals},
+                   RecScatter<KeyT>{skeys, svals, M, c->recpos.as<uint32_t>(), c->post.as<uint2>(), ghead}, d_scal + 0);
     uint64_t U = 0;
     { PinRead rd(c); const uint64_t *pu = rd.add<uint64_t>(d_scal + 0, 1); rd.sync(); U = *pu; }
     c->U = U;
     const uint32_t Uu = (uint32_t) U;
     const uint32_t ublocks = (Uu + 255) / 256;
-
-    c->post.alloc(U * sizeof(uint2));
     c->gid.alloc(U * sizeof(uint32_t));
     c->goff.alloc((U + 2) * sizeof(uint32_t));
-    uint8_t *ghead = reinterpret_cast<uint8_t *>(c->keys_a.p);   // keys_a is free after the sort (>= M bytes)
-    hipLaunchKernelGGL((k_build_records<KeyT>), dim3(ublocks), dim3(256), 0, st, skeys, svals, c->recpos.as<uint32_t>(), M, Uu,
-                       c->post.as<uint2>(), ghead);
     // K-groups
-    scan_and_apply(c, U, GroupHeadFlag{ghead}, GroupScatter{c->gid.as<uint32_t>(), c->goff.as<uint32_t>()}, d_scal + 1);
+    scan_and_apply(c, U, GroupHeadFlag{ghead, U}, GroupScatter{c->gid.as<uint32_t>(), c->goff.as<uint32_t>()}, d_scal + 1);
     hipLaunchKernelGGL(k_close_offsets, dim3(1), dim3(1), 0, st, c->goff.as<uint32_t>(), d_scal + 1, Uu);
     hipLaunchKernelGGL(k_fold_last_record, dim3(1), dim3(1024), 0, st, c->post.as<uint2>(), c->recpos.as<uint32_t>(), c->goff.as<uint32_t>(),
                        d_scal + 1, Uu);

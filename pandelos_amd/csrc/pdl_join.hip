@@ -132,7 +132,7 @@ __device__ __forceinline__ float finalize_cell(unsigned long long acc, uint32_t 
 //                   workgroups (rows) are resident per CU instead of one.
 // Rows whose keys do not fit are appended to an overflow list for the next tier.
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t BM_WORDS = 2048;                        // 65536-bit "seen once" bitmap
+constexpr uint32_t BM_WORDS = 1024;                        // 32768-bit "seen once" bitmap
 
 template <int HT_BITS_, int T_, bool FILTER>
 struct JoinCfg {
@@ -146,7 +146,7 @@ struct JoinCfg {
 };
 
 template <int HT_BITS_, int T_, bool FILTER>
-__global__ __launch_bounds__(T_) void k_join_lds(JoinArgs a) {
+__global__ __launch_bounds__(T_, (FILTER && HT_BITS_ == 10) ? 5 : 1) void k_join_lds(JoinArgs a) {
     using Cfg = JoinCfg<HT_BITS_, T_, FILTER>;
     constexpr uint32_t HT = Cfg::HT, LIMIT = Cfg::LIMIT, TOUCH_CAP = Cfg::TOUCH_CAP, RB = Cfg::RB, RPT = Cfg::RPT;
     constexpr int T = T_;
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(T_) void k_join_lds(JoinArgs a) {
 #pragma unroll
                     for (uint32_t u = 0; u < 4; u++) {       // four bitmap atomics in flight
                         ins[u] = live[u] && (!filter_on || max(po[u].y, gm[u].y) >= 2);
-                        const uint32_t h = (po[u].x * 0x9E3779B1u) >> 16;
+                        const uint32_t h = (po[u].x * 0x9E3779B1u) >> 17;
                         bit[u] = 1u << (h & 31);
                         old[u] = (live[u] && !ins[u]) ? atomicOr(&s_bm[h >> 5], bit[u]) : 0u;
                     }

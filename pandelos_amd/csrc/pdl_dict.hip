@@ -8,7 +8,7 @@
 //   K-sort    pdl_sort_pairs      stable LSD radix sort by rank              library.cpp:172-187,270-278
 //   K-rle     RecHead/RecScatter scan (records built in the apply)   dedup -> (rank,gene,count)   library.cpp:280-287
 //   K-groups  GroupHead scan, k_group_offsets, k_record_costs (+ the last-record fold)  library.cpp:297-335
-//   K-ranges  SharedScatter compaction, sort by gene, k_gather_ranges, k_seq_offsets, k_row_costs   library.cpp:312-327
+//   K-ranges  SharedScatter compaction, sort by gene, k_gather_ranges (+ per-gene cost), k_seq_offsets   library.cpp:312-327
 //   K-cost    k_genome_cost       per-genome and total lookups               library.cpp:337-350,535-538
 //
 // HBM layout after this stage (what the join reads):
@@ -27,15 +27,16 @@
 
 // ------------------------------------------------------------------------------------------------
 // K-hist: 256-bin histogram of the residue bytes (library.cpp:216-228).  16-byte coalesced loads,
-// per-workgroup LDS histogram (4 interleaved copies to thin out same-address atomics on
-// low-entropy input), one global atomic per non-empty bin per workgroup.
+// per-workgroup LDS histogram (8 copies, padded so that equal values of different copies fall in different
+// banks: protein input has ~20 distinct bytes), one global atomic per non-empty bin per workgroup — and few
+// workgroups, because those same-address device atomics serialise at the memory side (~11 ns each).
 // ------------------------------------------------------------------------------------------------
 constexpr int HIST_THREADS = 256;
 __global__ __launch_bounds__(HIST_THREADS) void k_hist(const uint8_t *__restrict__ res, uint64_t n, unsigned long long *__restrict__ hist) {
-    __shared__ uint32_t s_h[4][256];
-    for (int i = threadIdx.x; i < 4 * 256; i += HIST_THREADS) (&s_h[0][0])[i] = 0;
+    __shared__ uint32_t s_h[8][257];
+    for (int i = threadIdx.x; i < 8 * 257; i += HIST_THREADS) (&s_h[0][0])[i] = 0;
     __syncthreads();
-    const int copy = threadIdx.x & 3;
+    const int copy = threadIdx.x & 7;
     const uint64_t n16 = n / 16;
     const uint4 *res16 = reinterpret_cast<const uint4 *>(res);
     const uint64_t stride = (uint64_t) gridDim.x * HIST_THREADS;
@@ -55,7 +56,9 @@ __global__ __launch_bounds__(HIST_THREADS) void k_hist(const uint8_t *__restrict
     }
     __syncthreads();
     for (int b = threadIdx.x; b < 256; b += HIST_THREADS) {
-        uint32_t t = s_h[0][b] + s_h[1][b] + s_h[2][b] + s_h[3][b];
+        uint32_t t = 0;
+#pragma unroll
+        for (int cpy = 0; cpy < 8; cpy++) t += s_h[cpy][b];
         if (t) atomicAdd(&hist[b], (unsigned long long) t);
     }
 }
@@ -345,10 +348,33 @@ struct SharedScatter {
         tuples[prefix] = make_uint4(start, ge - start, po.y, ge - gs);      // {first posting, postings, own count, group size}
     }
 };
-__global__ __launch_bounds__(256) void k_gather_ranges(const uint32_t *__restrict__ idx_sorted, const uint4 *__restrict__ tuples,
-                                                       uint32_t n, uint4 *__restrict__ ranges) {
+// Also adds up total_visited (library.cpp:327) = the group sizes over a gene's ranges: the list is gene-sorted, so a
+// wave holds one or two genes as a rule; one atomic per (wave, gene).
+__global__ __launch_bounds__(256) void k_gather_ranges(const uint32_t *__restrict__ idx_sorted, const uint32_t *__restrict__ key_sorted,
+                                                       const uint4 *__restrict__ tuples, uint32_t n, uint4 *__restrict__ ranges,
+                                                       unsigned long long *__restrict__ cost) {
     const uint32_t e = blockIdx.x * 256 + threadIdx.x;
-    if (e < n) ranges[e] = tuples[idx_sorted[e]];
+    const uint32_t lane = threadIdx.x & (PDL_WAVE - 1);
+    const bool live = e < n;
+    uint32_t g = 0xffffffffu;
+    unsigned long long w = 0;
+    if (live) {
+        const uint4 t = tuples[idx_sorted[e]];
+        ranges[e] = t;
+        g = key_sorted[e];
+        w = t.w;
+    }
+    unsigned long long todo = __ballot(live);
+    while (todo) {
+        const int leader = __ffsll((long long) todo) - 1;
+        const uint32_t gl = __shfl(g, leader, PDL_WAVE);
+        const bool in = live && g == gl;
+        unsigned long long sum = in ? w : 0ull;
+#pragma unroll
+        for (int d = PDL_WAVE / 2; d > 0; d >>= 1) sum += __shfl_xor(sum, d, PDL_WAVE);
+        if ((int) lane == leader) atomicAdd(&cost[gl], sum);
+        todo &= ~__ballot(in);
+    }
 }
 // seq_off[s] = first range of gene s in the gene-sorted list (lower bound), seq_off[N] = number of ranges
 __global__ __launch_bounds__(256) void k_seq_offsets(const uint32_t *__restrict__ key_sorted, uint32_t n, uint32_t n_seq,
@@ -361,19 +387,6 @@ __global__ __launch_bounds__(256) void k_seq_offsets(const uint32_t *__restrict_
         if (key_sorted[mid] < s) lo = mid + 1; else hi = mid;
     }
     seq_off[s] = lo;
-}
-
-// total_visited (library.cpp:327) = sum of the group lengths over a gene's ranges; one wave per gene.
-__global__ __launch_bounds__(256) void k_row_costs(const uint4 *__restrict__ ranges, const uint32_t *__restrict__ seq_off,
-                                                   uint32_t n_seq, unsigned long long *__restrict__ cost) {
-    const uint32_t s = blockIdx.x * (256 / PDL_WAVE) + threadIdx.x / PDL_WAVE;
-    if (s >= n_seq) return;
-    const uint32_t lane = threadIdx.x & (PDL_WAVE - 1);
-    unsigned long long sum = 0;
-    for (uint32_t e = seq_off[s] + lane; e < seq_off[s + 1]; e += PDL_WAVE) sum += ranges[e].w;
-#pragma unroll
-    for (int d = PDL_WAVE / 2; d > 0; d >>= 1) sum += __shfl_down(sum, d, PDL_WAVE);
-    if (lane == 0) cost[s] += sum;      // on top of what the range-less last members of groups added
 }
 
 // K-cost: per-genome cost (library.cpp:535-538); the total is their sum (library.cpp:337-349).
@@ -514,11 +527,9 @@ static void dictionary_pipeline(pdl_ctx *c, bool only_complexity) {
         ev_begin(c, EV_RANGES);
         c->ranges.alloc(std::max<uint64_t>(Us, 1) * sizeof(uint4));
         c->seq_off.alloc(((size_t) c->N + 1) * sizeof(uint32_t));
-        if (Us) hipLaunchKernelGGL(k_gather_ranges, dim3(((uint32_t) Us + 255) / 256), dim3(256), 0, st, v2b, tuples, (uint32_t) Us,
-                                   c->ranges.as<uint4>());
+        if (Us) hipLaunchKernelGGL(k_gather_ranges, dim3(((uint32_t) Us + 255) / 256), dim3(256), 0, st, v2b, k2b, tuples, (uint32_t) Us,
+                                   c->ranges.as<uint4>(), c->cost.as<unsigned long long>());
         hipLaunchKernelGGL(k_seq_offsets, dim3((c->N + 1 + 255) / 256), dim3(256), 0, st, k2b, (uint32_t) Us, c->N, c->seq_off.as<uint32_t>());
-        hipLaunchKernelGGL(k_row_costs, dim3((c->N + 3) / 4), dim3(256), 0, st, c->ranges.as<uint4>(), c->seq_off.as<uint32_t>(),
-                           c->N, c->cost.as<unsigned long long>());
         PDL_HIP(hipGetLastError());
         ev_end(c, EV_RANGES);
     }
@@ -561,7 +572,7 @@ void pdl_run_preprocess(pdl_ctx *c, int kvalue, bool only_complexity) {
     ev_begin(c, EV_HIST);
     PDL_HIP(hipMemsetAsync(c->hist.p, 0, 256 * sizeof(uint64_t), st));
     if (c->R) {
-        uint32_t blocks = (uint32_t) std::min<uint64_t>((c->R / 16 + HIST_THREADS - 1) / HIST_THREADS + 1, 2048);
+        uint32_t blocks = (uint32_t) std::min<uint64_t>((c->R / 16 + HIST_THREADS - 1) / HIST_THREADS + 1, 256);
         hipLaunchKernelGGL(k_hist, dim3(blocks), dim3(HIST_THREADS), 0, st, c->d_res, c->R, c->hist.as<unsigned long long>());
     }
     // K-len (independent of the histogram)

@@ -73,6 +73,23 @@ def test_hip_matches_oracle_on_random_sets(shape, k):
         H.assert_scores_equal(nat.generate_scores_part(g).as_dict(), ora.scores(g), f"genome {g}")
 
 
+def test_rows_with_more_than_64_cells_take_the_workgroup_ordering_path():
+    """K-order ranks rows of <= 64 cells inside one wave and lists the larger ones for the LDS kernel: 100 genomes
+    sharing 3 gene families give every row ~100 cells; the emission order must still be the reference's."""
+    from oracle import binding as ob
+    from pandelos_amd.synth import make_gene_set
+    gs = make_gene_set(genomes=100, genes_per_genome=3, mean_len=90, sub_rate=0.04, seed=207)
+    nat = _native(gs.residues, gs.offsets, gs.genome_of, 4)
+    ora = ob.Oracle(gs.residues, gs.offsets, gs.genome_of, 4)
+    widest = 0
+    for g in range(ora.genomes):
+        got = nat.generate_scores_part(g).as_dict()
+        H.assert_scores_equal(got, ora.scores(g), f"genome {g}")
+        if len(got["row"]):
+            widest = max(widest, int(np.bincount(np.asarray(got["row"])).max()))
+    assert widest > 64
+
+
 def test_errors_mirror_reference_behaviour():
     from pandelos_amd import _lib
     res, off, gen, _, _ = H.load_small("readme4_k2")

@@ -609,6 +609,8 @@ __global__ __launch_bounds__(HBM_THREADS) void k_join_hbm(JoinArgs a) {
 // ------------------------------------------------------------------------------------------------
 constexpr int ORDER_THREADS = 256;
 constexpr int ORDER_TILE = 2048;
+constexpr uint32_t ORDER_CPL = 4;                              // cells per lane in the wave-per-row kernel
+constexpr uint32_t ORDER_WAVE_CELLS = ORDER_CPL * PDL_WAVE;    // rows up to this many cells are ranked inside one wave
 
 struct OrderArgs {
     const uint32_t *row_base, *row_cnt, *fin_off, *task_rows;
@@ -620,7 +622,6 @@ struct OrderArgs {
     int32_t *c_row, *c_col;
     uint32_t n_rows;
     uint32_t canonical;
-    uint32_t *big_rows, *n_big;         // rows of more than 64 cells: listed by k_order_rows_small for k_order_rows
 };
 
 __device__ __forceinline__ unsigned long long order_key_hi(uint32_t col, uint32_t first, uint32_t canonical) {
@@ -640,14 +641,12 @@ __device__ __forceinline__ OrderCell order_cell(const OrderArgs &a, uint32_t p, 
 __global__ __launch_bounds__(ORDER_THREADS) void k_order_rows(OrderArgs a) {
     __shared__ unsigned long long s_hi[ORDER_TILE];
     __shared__ uint32_t s_col[ORDER_TILE];
-  const uint32_t n_big = *a.n_big;
-  for (uint32_t bi = blockIdx.x; bi < n_big; bi += gridDim.x) {
-    const uint32_t p = a.big_rows[bi];
+    const uint32_t p = blockIdx.x;
     const uint32_t own = a.row_cnt[p];
     const uint32_t cnt = own + (a.mirror_cnt ? a.mirror_cnt[p] : 0u);
+    if (cnt <= ORDER_WAVE_CELLS) return;         // k_order_rows_wave's rows
     const uint32_t out0 = a.fin_off[p];
     const uint32_t row = a.task_rows[p];
-    __syncthreads();                             // the previous row's tiles are done with
     for (uint32_t i0 = 0; i0 < cnt; i0 += ORDER_THREADS) {
         const uint32_t i = i0 + threadIdx.x;
         const bool live = i < cnt;
@@ -687,43 +686,59 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_order_rows(OrderArgs a) {
             a.c_col[o] = (int32_t) col;
         }
     }
-  }
 }
 
-// Rows of at most 64 cells (nearly all of them): one wave per row, one cell per lane, the keys compared through
-// lane reads — no LDS, no barrier, four rows per workgroup.
-__global__ __launch_bounds__(256) void k_order_rows_small(OrderArgs a) {
+// Rows of at most 256 cells (nearly all rows of most datasets): one wave per row, up to four cells per lane, the keys
+// compared through lane reads — no LDS, no barrier, four rows per workgroup.
+__global__ __launch_bounds__(256) void k_order_rows_wave(OrderArgs a) {
     const uint32_t p = blockIdx.x * (256 / PDL_WAVE) + threadIdx.x / PDL_WAVE;
     if (p >= a.n_rows) return;
     const uint32_t lane = threadIdx.x & (PDL_WAVE - 1);
     const uint32_t own = a.row_cnt[p];
     const uint32_t cnt = own + (a.mirror_cnt ? a.mirror_cnt[p] : 0u);
-    if (cnt > PDL_WAVE && lane == 0) a.big_rows[atomicAdd(a.n_big, 1u)] = p;
-    if (cnt == 0 || cnt > PDL_WAVE) return;      // (wave-uniform)
-    const bool live = lane < cnt;
-    uint32_t col = 0, hi_lo = 0, hi_hi = 0;
-    OrderCell me{0, false};
-    if (live) {
-        me = order_cell(a, p, own, lane);
-        col = me.mirrored ? a.st_src[me.slot] : a.st_col[me.slot];
-        const unsigned long long hi = order_key_hi(col, a.st_first[me.slot], a.canonical);
-        hi_lo = (uint32_t) hi; hi_hi = (uint32_t) (hi >> 32);
+    if (cnt == 0 || cnt > ORDER_WAVE_CELLS) return;      // (wave-uniform)
+    const uint32_t nslots = (cnt + PDL_WAVE - 1) / PDL_WAVE;
+    uint32_t col[ORDER_CPL], hi_lo[ORDER_CPL], hi_hi[ORDER_CPL], rank[ORDER_CPL];
+    OrderCell me[ORDER_CPL];
+#pragma unroll
+    for (uint32_t s = 0; s < ORDER_CPL; s++) {
+        col[s] = 0; hi_lo[s] = 0; hi_hi[s] = 0; rank[s] = 0; me[s] = OrderCell{0, false};
+        const uint32_t i = s * PDL_WAVE + lane;
+        if (s < nslots && i < cnt) {
+            me[s] = order_cell(a, p, own, i);
+            col[s] = me[s].mirrored ? a.st_src[me[s].slot] : a.st_col[me[s].slot];
+            const unsigned long long hi = order_key_hi(col[s], a.st_first[me[s].slot], a.canonical);
+            hi_lo[s] = (uint32_t) hi; hi_hi[s] = (uint32_t) (hi >> 32);
+        }
     }
-    const unsigned long long hi = ((unsigned long long) hi_hi << 32) | hi_lo;
-    uint32_t rank = 0;
-    for (uint32_t j = 0; j < cnt; j++) {
-        const unsigned long long hj = ((unsigned long long) (uint32_t) __shfl((int) hi_hi, (int) j, PDL_WAVE) << 32) |
-                                      (uint32_t) __shfl((int) hi_lo, (int) j, PDL_WAVE);
-        const uint32_t cj = (uint32_t) __shfl((int) col, (int) j, PDL_WAVE);
-        rank += (hj < hi || (hj == hi && cj < col)) ? 1u : 0u;
+#pragma unroll
+    for (uint32_t sj = 0; sj < ORDER_CPL; sj++) {
+        if (sj >= nslots) break;
+        const uint32_t nj = min((uint32_t) PDL_WAVE, cnt - sj * PDL_WAVE);
+        for (uint32_t j = 0; j < nj; j++) {
+            const unsigned long long hj = ((unsigned long long) (uint32_t) __shfl((int) hi_hi[sj], (int) j, PDL_WAVE) << 32) |
+                                          (uint32_t) __shfl((int) hi_lo[sj], (int) j, PDL_WAVE);
+            const uint32_t cj = (uint32_t) __shfl((int) col[sj], (int) j, PDL_WAVE);
+#pragma unroll
+            for (uint32_t s = 0; s < ORDER_CPL; s++) {
+                const unsigned long long hi = ((unsigned long long) hi_hi[s] << 32) | hi_lo[s];
+                rank[s] += (hj < hi || (hj == hi && cj < col[s])) ? 1u : 0u;
+            }
+        }
     }
-    if (live) {
-        const uint32_t o = a.fin_off[p] + rank;
-        a.c_score[o] = a.st_score[me.slot];
-        a.c_perc[o] = me.mirrored ? a.st_tr[me.slot] : a.st_perc[me.slot];
-        a.c_tr[o] = me.mirrored ? a.st_perc[me.slot] : a.st_tr[me.slot];
-        a.c_row[o] = (int32_t) a.task_rows[p];
-        a.c_col[o] = (int32_t) col;
+    const uint32_t out0 = a.fin_off[p];
+    const int32_t row = (int32_t) a.task_rows[p];
+#pragma unroll
+    for (uint32_t s = 0; s < ORDER_CPL; s++) {
+        const uint32_t i = s * PDL_WAVE + lane;
+        if (s < nslots && i < cnt) {
+            const uint32_t o = out0 + rank[s];
+            a.c_score[o] = a.st_score[me[s].slot];
+            a.c_perc[o] = me[s].mirrored ? a.st_tr[me[s].slot] : a.st_perc[me[s].slot];
+            a.c_tr[o] = me[s].mirrored ? a.st_perc[me[s].slot] : a.st_tr[me[s].slot];
+            a.c_row[o] = row;
+            a.c_col[o] = (int32_t) col[s];
+        }
     }
 }
 
@@ -1002,9 +1017,8 @@ void pdl_run_score_all(pdl_ctx *c) {
         o.c_score = c->c_score.as<float>(); o.c_perc = c->c_perc.as<float>(); o.c_tr = c->c_tr.as<float>();
         o.c_row = c->c_row.as<int32_t>(); o.c_col = c->c_col.as<int32_t>();
         o.n_rows = n_rows; o.canonical = (c->flags & PDL_FLAG_CANONICAL_ORDER) ? 1u : 0u;
-        o.big_rows = list_a; o.n_big = ctr32 + 8;       // list A is free once the tiers have run
-        hipLaunchKernelGGL(k_order_rows_small, dim3((n_rows + 3) / 4), dim3(256), 0, st, o);
-        hipLaunchKernelGGL(k_order_rows, dim3(std::min<uint32_t>(n_rows, (uint32_t) cus * 8)), dim3(ORDER_THREADS), 0, st, o);
+        hipLaunchKernelGGL(k_order_rows_wave, dim3((n_rows + 3) / 4), dim3(256), 0, st, o);
+        hipLaunchKernelGGL(k_order_rows, dim3(n_rows), dim3(ORDER_THREADS), 0, st, o);     // rows of more than 256 cells; the others leave at once
         PDL_HIP(hipGetLastError());
         ev_end(c, EV_ORDER);
 

@@ -73,12 +73,13 @@ def test_hip_matches_oracle_on_random_sets(shape, k):
         H.assert_scores_equal(nat.generate_scores_part(g).as_dict(), ora.scores(g), f"genome {g}")
 
 
-def test_rows_with_more_than_64_cells_take_the_workgroup_ordering_path():
-    """K-order ranks rows of <= 64 cells inside one wave and lists the larger ones for the LDS kernel: 100 genomes
-    sharing 3 gene families give every row ~100 cells; the emission order must still be the reference's."""
+@pytest.mark.parametrize("genomes,floor", [(100, 64), (300, 256)])
+def test_wide_rows_keep_the_reference_emission_order(genomes, floor):
+    """K-order ranks rows of <= 256 cells inside one wave (up to 4 cells per lane) and the wider ones in the LDS
+    kernel: `genomes` genomes sharing 3 gene families give every row ~`genomes` cells."""
     from oracle import binding as ob
     from pandelos_amd.synth import make_gene_set
-    gs = make_gene_set(genomes=100, genes_per_genome=3, mean_len=90, sub_rate=0.04, seed=207)
+    gs = make_gene_set(genomes=genomes, genes_per_genome=3, mean_len=90, sub_rate=0.04, seed=207)
     nat = _native(gs.residues, gs.offsets, gs.genome_of, 4)
     ora = ob.Oracle(gs.residues, gs.offsets, gs.genome_of, 4)
     widest = 0
@@ -87,7 +88,7 @@ def test_rows_with_more_than_64_cells_take_the_workgroup_ordering_path():
         H.assert_scores_equal(got, ora.scores(g), f"genome {g}")
         if len(got["row"]):
             widest = max(widest, int(np.bincount(np.asarray(got["row"])).max()))
-    assert widest > 64
+    assert widest > floor
 
 
 def test_errors_mirror_reference_behaviour():

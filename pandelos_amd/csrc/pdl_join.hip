@@ -50,7 +50,6 @@ struct JoinArgs {
     uint32_t N, G, k;
     uint32_t min_kseq;             // smallest non-zero kseq_length of the dataset (finalize pre-filter)
     uint32_t canonical;            // PDL_FLAG_CANONICAL_ORDER: no first-touch tracking
-    uint32_t debug;                // PDL_JOIN_DEBUG (timing experiments only): 1 skip table ops, 2 skip posting loads, 4 skip finalize
     float *MS;                     // [n_task_rows][G]
     float *CM;                     // [shard][N]
     uint32_t *row_base, *row_cnt;  // [n_task_rows]
@@ -245,7 +244,6 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ == 10) ? 5 : 1) void k_join
     // inside the chunk are turned into a 64-bit boundary mask with scalar ops, and a lane's range is rs +
     // popcount(boundaries at or below the lane), its offset the distance to the last such boundary.
     auto walk = [&](uint32_t total, auto &&fn4) {
-        if (a.debug & 8) return;
         constexpr uint32_t NW = T / PDL_WAVE;
         const uint32_t lane = tid & (PDL_WAVE - 1), wave = tid / PDL_WAVE;
         const uint32_t chunks = (total + PDL_WAVE - 1) / PDL_WAVE;
@@ -287,14 +285,8 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ == 10) ? 5 : 1) void k_join
                 }
             }
 #pragma unroll
-            for (uint32_t u = 0; u < 4; u++)
-                if (live[u]) po[u] = (a.debug & 2) ? make_uint2(adr[u] % a.N, 1u) : a.post[adr[u]];
-            if (a.debug & 1) {
-#pragma unroll
-                for (uint32_t u = 0; u < 4; u++) if (live[u] && po[u].x == 0xfffffff0u) s_overflow = 1;
-            } else {
-                fn4(po, gm, gsv, live);
-            }
+            for (uint32_t u = 0; u < 4; u++) po[u] = a.post[live[u] ? adr[u] : 0u];     // dead lanes (last chunk) read posting 0: no exec juggling
+            fn4(po, gm, gsv, live);
         }
     };
 
@@ -316,7 +308,7 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ == 10) ? 5 : 1) void k_join
             }
             if (next_reg < n_work) next_desc = a.desc[next_reg];
         }
-        const uint32_t p = d.x, r = d.y, e0 = d.z, nr = (a.debug & 16) ? 0u : d.w;
+        const uint32_t p = d.x, r = d.y, e0 = d.z, nr = d.w;
         if (nr == 0) {                                   // gene shares no k-mer group: no candidates
             if (tid == 0) { a.row_base[p] = 0; a.row_cnt[p] = 0; s_next = next_reg; s_desc = next_desc; }
             continue;
@@ -424,7 +416,6 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ == 10) ? 5 : 1) void k_join
             const uint32_t c = kf.x;
             const unsigned long long acc = s_acc[slot];
             s_kf[slot] = make_uint2(EMPTY_KEY, 0u); s_acc[slot] = 0;        // slot consumed
-            if (a.debug & 4) continue;
             if (c >= a.N) { atomicAdd(a.error_count, 1u); continue; }       // a listed slot must hold a column id
             if (c == r) continue;                         // identity cell is zeroed (library.cpp:485-487)
             // score_valid needs perc >= thr or tr_perc >= thr (library.cpp:497-500).  Both quotients are monotone
@@ -945,7 +936,6 @@ void pdl_run_score_all(pdl_ctx *c) {
         a.task_rows = c->task_rows.as<uint32_t>(); a.task_lg = c->task_lg.as<uint32_t>();
         a.N = N; a.G = G; a.k = c->rp.k;
         a.min_kseq = (uint32_t) std::max<uint64_t>(c->min_kseq, 1); a.canonical = (c->flags & PDL_FLAG_CANONICAL_ORDER) ? 1u : 0u;
-        if (const char *e = getenv("PDL_JOIN_DEBUG")) a.debug = (uint32_t) atoi(e);
         a.MS = c->MS.as<float>(); a.CM = c->CM.as<float>();
         a.row_base = c->row_base.as<uint32_t>(); a.row_cnt = c->row_cnt.as<uint32_t>();
         a.st_score = c->st_score.as<float>(); a.st_perc = c->st_perc.as<float>(); a.st_tr = c->st_tr.as<float>();

@@ -62,6 +62,7 @@ void pdl_destroy(pdl_ctx *c) {
     for (auto &e : c->ev) { if (e.a) (void) hipEventDestroy(e.a); if (e.b) (void) hipEventDestroy(e.b); }
     if (c->own_stream && c->stream) (void) hipStreamDestroy(c->stream);
     if (c->pin) (void) hipHostFree(c->pin);
+    if (c->mirror) (void) hipHostFree(c->mirror);
     delete c;
 }
 
@@ -208,6 +209,7 @@ static int score_all_locked(pdl_ctx *c) {
     if (c->only_complexity) PDL_FAIL(PDL_ERR_STATE, "the dictionary was built in complexity-only mode (no posting ranges)");
     if (c->scored) return PDL_OK;
     PDL_HIP(hipSetDevice(c->device));
+    c->mirror_valid = false;
     pdl_run_score_all(c);
     return PDL_OK;
     PDL_GUARD_END(c)
@@ -262,16 +264,47 @@ int pdl_compute_scores(pdl_ctx *c, uint32_t genome, pdl_scores *out) {
     out->max_genome_score = xalloc<float>((size_t) rows * G);
     out->max_genome_score_col = xalloc<float>(N);
     out->scoresMaxMappings = xalloc<int32_t>(N);
-    if (z) {
-        PDL_HIP(hipMemcpyAsync(out->scores, c->c_score.as<float>() + z0, (size_t) z * 4, hipMemcpyDeviceToHost, st));
-        PDL_HIP(hipMemcpyAsync(out->percs, c->c_perc.as<float>() + z0, (size_t) z * 4, hipMemcpyDeviceToHost, st));
-        PDL_HIP(hipMemcpyAsync(out->tr_percs, c->c_tr.as<float>() + z0, (size_t) z * 4, hipMemcpyDeviceToHost, st));
-        PDL_HIP(hipMemcpyAsync(out->row, c->c_row.as<int32_t>() + z0, (size_t) z * 4, hipMemcpyDeviceToHost, st));
-        PDL_HIP(hipMemcpyAsync(out->column, c->c_col.as<int32_t>() + z0, (size_t) z * 4, hipMemcpyDeviceToHost, st));
+    // Results up to PDL_MIRROR_LIMIT come to the host once, into pinned memory, with one copy per array; the per-genome
+    // calls (the reference's thread pool makes G of them, Pangenes.java:54-66) then only slice that mirror.
+    const uint64_t Zall = c->h_cell_off.back();
+    const size_t S = c->shard.size();
+    const size_t b_cells = (size_t) Zall * 4, b_ms = (size_t) c->n_task_rows * G * 4, b_cm = S * (size_t) N * 4;
+    const size_t need = 5 * b_cells + b_ms + b_cm;
+    constexpr size_t PDL_MIRROR_LIMIT = (size_t) 1 << 30;
+    const char *mirror_env = getenv("PDL_HOST_MIRROR");          // "0": per-genome device copies (the path of larger results), for tests
+    if (need <= PDL_MIRROR_LIMIT && !(mirror_env && mirror_env[0] == '0')) {
+        if (!c->mirror_valid) {
+            if (c->mirror_bytes < need) {
+                if (c->mirror) { (void) hipHostFree(c->mirror); c->mirror = nullptr; c->mirror_bytes = 0; }
+                PDL_HIP(hipHostMalloc((void **) &c->mirror, need + need / 4 + 64, hipHostMallocDefault));
+                c->mirror_bytes = need + need / 4 + 64;
+            }
+            uint8_t *m = c->mirror;
+            const void *src[5] = {c->c_score.p, c->c_perc.p, c->c_tr.p, c->c_row.p, c->c_col.p};
+            for (int i = 0; i < 5; i++)
+                if (b_cells) PDL_HIP(hipMemcpyAsync(m + (size_t) i * b_cells, src[i], b_cells, hipMemcpyDeviceToHost, st));
+            if (b_ms) PDL_HIP(hipMemcpyAsync(m + 5 * b_cells, c->MS.p, b_ms, hipMemcpyDeviceToHost, st));
+            if (b_cm) PDL_HIP(hipMemcpyAsync(m + 5 * b_cells + b_ms, c->CM.p, b_cm, hipMemcpyDeviceToHost, st));
+            PDL_HIP(hipStreamSynchronize(st));
+            c->mirror_valid = true;
+        }
+        const uint8_t *m = c->mirror;
+        void *dst[5] = {out->scores, out->percs, out->tr_percs, out->row, out->column};
+        for (int i = 0; i < 5; i++) if (z) memcpy(dst[i], m + (size_t) i * b_cells + (size_t) z0 * 4, (size_t) z * 4);
+        if (rows) memcpy(out->max_genome_score, m + 5 * b_cells + (size_t) p0 * G * 4, (size_t) rows * G * 4);
+        memcpy(out->max_genome_score_col, m + 5 * b_cells + b_ms + (size_t) lg * N * 4, (size_t) N * 4);
+    } else {
+        if (z) {
+            PDL_HIP(hipMemcpyAsync(out->scores, c->c_score.as<float>() + z0, (size_t) z * 4, hipMemcpyDeviceToHost, st));
+            PDL_HIP(hipMemcpyAsync(out->percs, c->c_perc.as<float>() + z0, (size_t) z * 4, hipMemcpyDeviceToHost, st));
+            PDL_HIP(hipMemcpyAsync(out->tr_percs, c->c_tr.as<float>() + z0, (size_t) z * 4, hipMemcpyDeviceToHost, st));
+            PDL_HIP(hipMemcpyAsync(out->row, c->c_row.as<int32_t>() + z0, (size_t) z * 4, hipMemcpyDeviceToHost, st));
+            PDL_HIP(hipMemcpyAsync(out->column, c->c_col.as<int32_t>() + z0, (size_t) z * 4, hipMemcpyDeviceToHost, st));
+        }
+        if (rows) PDL_HIP(hipMemcpyAsync(out->max_genome_score, c->MS.as<float>() + (size_t) p0 * G, (size_t) rows * G * 4, hipMemcpyDeviceToHost, st));
+        PDL_HIP(hipMemcpyAsync(out->max_genome_score_col, c->CM.as<float>() + (size_t) lg * N, (size_t) N * 4, hipMemcpyDeviceToHost, st));
+        PDL_HIP(hipStreamSynchronize(st));
     }
-    if (rows) PDL_HIP(hipMemcpyAsync(out->max_genome_score, c->MS.as<float>() + (size_t) p0 * G, (size_t) rows * G * 4, hipMemcpyDeviceToHost, st));
-    PDL_HIP(hipMemcpyAsync(out->max_genome_score_col, c->CM.as<float>() + (size_t) lg * N, (size_t) N * 4, hipMemcpyDeviceToHost, st));
-    PDL_HIP(hipStreamSynchronize(st));
     // library.cpp:571-575: genome of row / column per cell;  :428-432: flat map
     for (uint32_t i = 0; i < z; i++) {
         out->first_seq_genome[i] = (int32_t) c->h_genome_of[out->row[i]];

@@ -159,6 +159,11 @@ struct pdl_ctx {
     EventPair ev[12];
     uint8_t *pin = nullptr;       // pinned host scratch for the small device->host reads (true async DMA, no staging copy)
     size_t pin_bytes = 0;
+    // host mirror of the whole scoring result (pinned): filled by ONE set of device->host copies at the first
+    // pdl_compute_scores after a scoring pass, so the per-genome calls are host memcpys (results up to PDL_MIRROR_LIMIT)
+    uint8_t *mirror = nullptr;
+    size_t mirror_bytes = 0;
+    bool mirror_valid = false;
 };
 
 // Small device->host reads through the pinned scratch: queue with add(), one sync(), then read the returned pointers.

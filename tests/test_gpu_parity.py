@@ -91,6 +91,17 @@ def test_wide_rows_keep_the_reference_emission_order(genomes, floor):
     assert widest > floor
 
 
+def test_per_genome_device_copies_equal_the_host_mirror(monkeypatch):
+    """pdl_compute_scores slices a pinned host mirror of the whole result (<= 1 GiB) or, for larger results, copies each
+    genome's block from the device; PDL_HOST_MIRROR=0 forces the second path."""
+    res, off, gen, k, fx = H.load_small(H.SMALL_CASES[0])
+    nat = _native(res, off, gen, k)
+    H.assert_scores_equal_fixture(lambda g: nat.generate_scores_part(g).as_dict(), fx, nat.cost.genomes, "mirror")
+    monkeypatch.setenv("PDL_HOST_MIRROR", "0")
+    nat2 = _native(res, off, gen, k)
+    H.assert_scores_equal_fixture(lambda g: nat2.generate_scores_part(g).as_dict(), fx, nat2.cost.genomes, "device copies")
+
+
 def test_errors_mirror_reference_behaviour():
     from pandelos_amd import _lib
     res, off, gen, _, _ = H.load_small("readme4_k2")

@@ -131,7 +131,6 @@ __device__ __forceinline__ float finalize_cell(unsigned long long acc, uint32_t 
 //                   workgroups (rows) are resident per CU instead of one.
 // Rows whose keys do not fit are appended to an overflow list for the next tier.
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t BM_WORDS = 1024;                        // 32768-bit "seen once" bitmap
 
 template <int HT_BITS_, int T_, bool FILTER>
 struct JoinCfg {
@@ -140,6 +139,10 @@ struct JoinCfg {
     static constexpr uint32_t TOUCH_CAP = LIMIT + T_;      // < HT: the probe loop always finds a free slot
     static constexpr uint32_t RPT = FILTER ? 2 : 1;        // ranges staged per thread and batch
     static constexpr uint32_t RB = RPT * T_;
+    // "seen once" bitmap of the filter tier: 32 Kbit beside the 1024-slot table (keeps five workgroups per CU), 64 Kbit
+    // beside the larger tables, whose rows hold far more lookups (a full bitmap filters nothing and overflows the table)
+    static constexpr uint32_t BM_BITS_LOG2 = HT_BITS_ <= 10 ? 15 : 16;
+    static constexpr uint32_t BM_WORDS = (1u << BM_BITS_LOG2) / 32;
     static_assert(TOUCH_CAP < HT, "table must never fill up");
     static_assert(TOUCH_CAP <= CELL_CHUNK, "a staging chunk must hold any row");
 };
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ == 10) ? 5 : 1) void k_join
     constexpr int T = T_;
     __shared__ unsigned long long s_acc[HT];
     __shared__ uint2 s_kf[HT];                       // {column id, 0xffffffff - smallest group start that touched it}
-    __shared__ uint32_t s_bm[FILTER ? BM_WORDS : 1];
+    __shared__ uint32_t s_bm[FILTER ? Cfg::BM_WORDS : 1];
     __shared__ uint16_t s_touched[TOUCH_CAP];
     __shared__ uint2 s_gm[RB + 1];                   // staged ranges: {first posting, own count}
     __shared__ uint32_t s_gsv[RB + 1];               // and the start of their group (identifies the group: emission order)
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ == 10) ? 5 : 1) void k_join
         } else {
             // single-sighting columns may be dropped only if nobody involved has <= 2k k-mers
             const bool filter_on = my_kcnt > 2 * a.k && a.min_kseq > 2 * a.k;
-            for (uint32_t i = tid; i < BM_WORDS / 4; i += T) reinterpret_cast<uint4 *>(s_bm)[i] = make_uint4(0, 0, 0, 0);
+            for (uint32_t i = tid; i < Cfg::BM_WORDS / 4; i += T) reinterpret_cast<uint4 *>(s_bm)[i] = make_uint4(0, 0, 0, 0);
             uint32_t total = 0;
             for (uint32_t b0 = 0; b0 < nr; b0 += RB) {       // pass 1: which columns need a slot
                 total = stage(e0, b0, min(RB, nr - b0));     // (its barriers also cover the bitmap clear)
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ == 10) ? 5 : 1) void k_join
 #pragma unroll
                     for (uint32_t u = 0; u < 4; u++) {       // four bitmap atomics in flight
                         ins[u] = live[u] && (!filter_on || max(po[u].y, gm[u].y) >= 2);
-                        const uint32_t h = (po[u].x * 0x9E3779B1u) >> 17;
+                        const uint32_t h = (po[u].x * 0x9E3779B1u) >> (32 - Cfg::BM_BITS_LOG2);
                         bit[u] = 1u << (h & 31);
                         old[u] = (live[u] && !ins[u]) ? atomicOr(&s_bm[h >> 5], bit[u]) : 0u;
                     }
@@ -638,6 +641,51 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_order_rows(OrderArgs a) {
     if (cnt <= ORDER_WAVE_CELLS) return;         // k_order_rows_wave's rows
     const uint32_t out0 = a.fin_off[p];
     const uint32_t row = a.task_rows[p];
+    if (cnt <= ORDER_TILE) {
+        // bitonic sort of the row's keys in LDS (keys are unique: the column is part of them); position q of the sorted
+        // order then fetches its cell and writes output slot q — coalesced writes, O(n log^2 n) compares
+        __shared__ uint16_t s_idx[ORDER_TILE];
+        uint32_t n2 = 512;
+        while (n2 < cnt) n2 <<= 1;
+        for (uint32_t j = threadIdx.x; j < n2; j += ORDER_THREADS) {
+            if (j < cnt) {
+                const OrderCell oc = order_cell(a, p, own, j);
+                const uint32_t cj = oc.mirrored ? a.st_src[oc.slot] : a.st_col[oc.slot];
+                s_col[j] = cj;
+                s_hi[j] = order_key_hi(cj, a.st_first[oc.slot], a.canonical);
+            } else {
+                s_col[j] = 0xffffffffu; s_hi[j] = ~0ull;         // padding sorts last
+            }
+            s_idx[j] = (uint16_t) j;
+        }
+        __syncthreads();
+        for (uint32_t k = 2; k <= n2; k <<= 1) {
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t t = threadIdx.x; t < n2 / 2; t += ORDER_THREADS) {
+                    const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi_i = lo | j;
+                    const bool up = (lo & k) == 0;               // ascending block
+                    const unsigned long long ha = s_hi[lo], hb = s_hi[hi_i];
+                    const uint32_t ca = s_col[lo], cb = s_col[hi_i];
+                    const bool a_gt_b = ha > hb || (ha == hb && ca > cb);
+                    if (a_gt_b == up) {
+                        s_hi[lo] = hb; s_hi[hi_i] = ha; s_col[lo] = cb; s_col[hi_i] = ca;
+                        const uint16_t ia = s_idx[lo]; s_idx[lo] = s_idx[hi_i]; s_idx[hi_i] = ia;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        for (uint32_t q = threadIdx.x; q < cnt; q += ORDER_THREADS) {
+            const OrderCell me = order_cell(a, p, own, s_idx[q]);
+            const uint32_t o = out0 + q;
+            a.c_score[o] = a.st_score[me.slot];
+            a.c_perc[o] = me.mirrored ? a.st_tr[me.slot] : a.st_perc[me.slot];
+            a.c_tr[o] = me.mirrored ? a.st_perc[me.slot] : a.st_tr[me.slot];
+            a.c_row[o] = (int32_t) row;
+            a.c_col[o] = (int32_t) s_col[q];
+        }
+        return;
+    }
     for (uint32_t i0 = 0; i0 < cnt; i0 += ORDER_THREADS) {
         const uint32_t i = i0 + threadIdx.x;
         const bool live = i < cnt;

@@ -73,13 +73,14 @@ def test_hip_matches_oracle_on_random_sets(shape, k):
         H.assert_scores_equal(nat.generate_scores_part(g).as_dict(), ora.scores(g), f"genome {g}")
 
 
-@pytest.mark.parametrize("genomes,floor", [(100, 64), (300, 256)])
-def test_wide_rows_keep_the_reference_emission_order(genomes, floor):
-    """K-order ranks rows of <= 256 cells inside one wave (up to 4 cells per lane) and the wider ones in the LDS
-    kernel: `genomes` genomes sharing 3 gene families give every row ~`genomes` cells."""
+@pytest.mark.parametrize("genomes,per_genome,floor", [(100, 3, 64), (300, 3, 256), (2100, 1, 2048)])
+def test_wide_rows_keep_the_reference_emission_order(genomes, per_genome, floor):
+    """K-order ranks rows of <= 256 cells inside one wave (up to 4 cells per lane), rows of <= 2048 cells with a bitonic
+    sort in LDS, and anything wider by counting: `genomes` genomes sharing the same gene families give every row
+    ~`genomes` cells."""
     from oracle import binding as ob
     from pandelos_amd.synth import make_gene_set
-    gs = make_gene_set(genomes=genomes, genes_per_genome=3, mean_len=90, sub_rate=0.04, seed=207)
+    gs = make_gene_set(genomes=genomes, genes_per_genome=per_genome, mean_len=90, sub_rate=0.04, seed=207)
     nat = _native(gs.residues, gs.offsets, gs.genome_of, 4)
     ora = ob.Oracle(gs.residues, gs.offsets, gs.genome_of, 4)
     widest = 0

@@ -331,7 +331,7 @@ struct SharedFlag {
 };
 struct SharedScatter {
     const uint2 *post; const uint32_t *gid; const uint32_t *goff;
-    uint32_t *key2; uint32_t *val2; uint4 *tuples;
+    uint32_t *key2; uint4 *tuples;
     uint32_t upper_only;       // 1: a gene's range covers only the postings AFTER its own record (genes above it)
     unsigned long long *cost;  // upper_only: the group size of a group's last member is added here (it has no range)
     __device__ void operator()(uint64_t u, uint32_t f, uint32_t prefix) const {
@@ -343,8 +343,7 @@ struct SharedScatter {
         }
         const uint2 po = post[u];
         const uint32_t start = upper_only ? (uint32_t) u + 1 : gs;
-        key2[prefix] = po.x;
-        val2[prefix] = prefix;
+        key2[prefix] = po.x;             // (the sort's values are the positions themselves)
         tuples[prefix] = make_uint4(start, ge - start, po.y, ge - gs);      // {first posting, postings, own count, group size}
     }
 };
@@ -515,13 +514,13 @@ static void dictionary_pipeline(pdl_ctx *c, bool only_complexity) {
         const uint32_t upper_only = c->dict_shard.empty() ? 1u : 0u;
         PDL_HIP(hipMemsetAsync(c->cost.p, 0, (size_t) c->N * sizeof(uint64_t), st));
         scan_and_apply(c, U, SharedFlag{c->gid.as<uint32_t>(), c->goff.as<uint32_t>(), c->post.as<uint2>(), in_shard, upper_only},
-                       SharedScatter{c->post.as<uint2>(), c->gid.as<uint32_t>(), c->goff.as<uint32_t>(), k2a, v2a, tuples,
+                       SharedScatter{c->post.as<uint2>(), c->gid.as<uint32_t>(), c->goff.as<uint32_t>(), k2a, tuples,
                                      upper_only, c->cost.as<unsigned long long>()}, d_scal + 2);
         c->upper_only = upper_only != 0;
         uint64_t Us = 0;
         { PinRead rd(c); const uint64_t *pu = rd.add<uint64_t>(d_scal + 2, 1); rd.sync(); Us = *pu; }
         const uint32_t seq_bits = std::max<uint32_t>(1, bit_length64(c->N ? c->N - 1 : 0));
-        pdl_sort_pairs<uint32_t>(c, k2a, k2b, v2a, v2b, Us, seq_bits);     // sorted pairs now in (k2b, v2b)
+        pdl_sort_pairs<uint32_t>(c, k2a, k2b, v2a, v2b, Us, seq_bits, true);     // values = tuple positions; sorted pairs now in (k2b, v2b)
         ev_end(c, EV_SORT2);
 
         ev_begin(c, EV_RANGES);

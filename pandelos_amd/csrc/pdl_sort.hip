@@ -58,7 +58,7 @@ struct RsOffsApply {
 };
 
 template <class KeyT>
-__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const KeyT *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const KeyT *__restrict__ keys_in, const uint32_t *vals_in,
                                                            KeyT *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint64_t n,
                                                            uint32_t shift, uint32_t n_tiles, const uint32_t *__restrict__ offs) {
     __shared__ KeyT s_key[RS_TILE];
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const KeyT *__restric
         const uint64_t i = wave_base + (uint64_t) j * PDL_WAVE + lane;
         const bool valid = i < n;
         key[j] = valid ? keys_in[i] : (KeyT) 0;
-        val[j] = valid ? vals_in[i] : 0u;
+        val[j] = valid ? (vals_in ? vals_in[i] : (uint32_t) i) : 0u;     // vals_in == nullptr: the values are the positions 0, 1, 2, ...
         const uint32_t d = rs_digit(key[j], shift);
         unsigned long long same = __ballot(valid);
 #pragma unroll
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const KeyT *__restric
 
 template <class KeyT>
 void pdl_sort_pairs(pdl_ctx *c, KeyT *&keys_in, KeyT *&keys_out, uint32_t *&vals_in, uint32_t *&vals_out,
-                    uint64_t n, uint32_t end_bit) {
+                    uint64_t n, uint32_t end_bit, bool iota_values) {
     if (n == 0) return;
     if (end_bit == 0) end_bit = 1;
     if (end_bit > sizeof(KeyT) * 8) end_bit = sizeof(KeyT) * 8;
@@ -150,8 +150,8 @@ void pdl_sort_pairs(pdl_ctx *c, KeyT *&keys_in, KeyT *&keys_out, uint32_t *&vals
         const uint32_t shift = p * 8;
         hipLaunchKernelGGL((k_rs_hist<KeyT>), dim3(n_tiles), dim3(RS_THREADS), 0, c->stream, keys_in, n, shift, n_tiles, counts);
         scan_and_apply(c, table, RsCountFlag{counts}, RsOffsApply{offs}, d_total);
-        hipLaunchKernelGGL((k_rs_scatter<KeyT>), dim3(n_tiles), dim3(RS_THREADS), 0, c->stream, keys_in, vals_in, keys_out, vals_out, n,
-                           shift, n_tiles, offs);
+        hipLaunchKernelGGL((k_rs_scatter<KeyT>), dim3(n_tiles), dim3(RS_THREADS), 0, c->stream, keys_in,
+                           (p == 0 && iota_values) ? (const uint32_t *) nullptr : vals_in, keys_out, vals_out, n, shift, n_tiles, offs);
         PDL_HIP(hipGetLastError());
         std::swap(keys_in, keys_out);
         std::swap(vals_in, vals_out);
@@ -162,5 +162,5 @@ void pdl_sort_pairs(pdl_ctx *c, KeyT *&keys_in, KeyT *&keys_out, uint32_t *&vals
     std::swap(vals_in, vals_out);
 }
 
-template void pdl_sort_pairs<uint32_t>(pdl_ctx *, uint32_t *&, uint32_t *&, uint32_t *&, uint32_t *&, uint64_t, uint32_t);
-template void pdl_sort_pairs<uint64_t>(pdl_ctx *, uint64_t *&, uint64_t *&, uint32_t *&, uint32_t *&, uint64_t, uint32_t);
+template void pdl_sort_pairs<uint32_t>(pdl_ctx *, uint32_t *&, uint32_t *&, uint32_t *&, uint32_t *&, uint64_t, uint32_t, bool);
+template void pdl_sort_pairs<uint64_t>(pdl_ctx *, uint64_t *&, uint64_t *&, uint32_t *&, uint32_t *&, uint64_t, uint32_t, bool);

@@ -262,6 +262,34 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ == 10) ? 5 : 1) void k_join
             uint2 gm[4], po[4];
             uint32_t adr[4], gsv[4];
             bool live[4];
+            const uint32_t nu = min(4u, ch_end - ch);                    // chunks of this iteration (wave-uniform)
+            const uint32_t f_lo = ch * PDL_WAVE, f_hi = f_lo + nu * PDL_WAVE;
+            // ONE read of the next 64 range starts serves all four chunks when it reaches past them (always, unless
+            // the ranges average under 4 postings): the four lane->range mappings then do not wait for each other.
+            const uint32_t vw = s_cum[rs + 1 + lane];                    // starts of the following ranges (all > f_lo)
+            if (__builtin_amdgcn_readlane(vw, PDL_WAVE - 1) >= f_hi) {
+#pragma unroll
+                for (uint32_t u = 0; u < 4; u++) {
+                    live[u] = false;
+                    if (u < nu) {                                        // wave-uniform
+                        const uint32_t lo = f_lo + u * PDL_WAVE, f = lo + lane;
+                        const uint32_t cu = (uint32_t) __popcll(__ballot(vw <= lo));       // ranges that begin at or before the chunk
+                        const uint32_t start_u = cu ? __builtin_amdgcn_readlane(vw, cu - 1) : cum_rs;
+                        const bool inside = vw > lo && vw < lo + PDL_WAVE;
+                        const int recv = __builtin_amdgcn_ds_permute((int) ((inside ? vw - lo : 0u) << 2), inside ? 1 : 0);
+                        const unsigned long long m = __ballot(recv != 0);
+                        const unsigned long long below = m & ((2ull << lane) - 1ull);
+                        const uint32_t r = rs + cu + (uint32_t) __popcll(below);
+                        const uint32_t off = below ? lane - (63u - (uint32_t) __clzll((long long) below)) : f - start_u;
+                        live[u] = f < total;
+                        gm[u] = s_gm[r];
+                        gsv[u] = s_gsv[r];
+                        adr[u] = gm[u].x + off;
+                    }
+                }
+                const uint32_t ce = (uint32_t) __popcll(__ballot(vw <= f_hi));             // range holding the next iteration's first lookup
+                if (ce) { cum_rs = __builtin_amdgcn_readlane(vw, ce - 1); rs += ce; }
+            } else {
 #pragma unroll
             for (uint32_t u = 0; u < 4; u++) {
                 live[u] = false;
@@ -286,6 +314,7 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ == 10) ? 5 : 1) void k_join
                     if (nextb == f0 + PDL_WAVE) { rs += w + 1; cum_rs = nextb; }
                     else if (w) { cum_rs = __builtin_amdgcn_readlane(v, w - 1); rs += w; }
                 }
+            }
             }
 #pragma unroll
             for (uint32_t u = 0; u < 4; u++) po[u] = a.post[live[u] ? adr[u] : 0u];     // dead lanes (last chunk) read posting 0: no exec juggling

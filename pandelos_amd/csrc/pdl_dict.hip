@@ -502,13 +502,13 @@ static void dictionary_pipeline(pdl_ctx *c, bool only_complexity) {
         uint32_t *v2b = k2b + U;
         const uint8_t *in_shard = nullptr;
         if (!c->dict_shard.empty()) {       // multi-GPU: only the genes this context scores need range lists
-            std::vector<uint8_t> h((size_t) c->N, 0);
+            std::vector<uint8_t> &h = c->h_seq_in_shard;   // lives in the context: the copy below needs no synchronisation
+            h.assign((size_t) c->N, 0);
             std::vector<uint8_t> gsel((size_t) c->G, 0);
             for (uint32_t g : c->dict_shard) gsel[g] = 1;
             for (uint32_t i = 0; i < c->N; i++) h[i] = gsel[c->h_genome_of[i]];
             c->seq_in_shard.alloc(c->N);
             PDL_HIP(hipMemcpyAsync(c->seq_in_shard.p, h.data(), c->N, hipMemcpyHostToDevice, st));
-            PDL_HIP(hipStreamSynchronize(st));
             in_shard = c->seq_in_shard.as<uint8_t>();
         }
         const uint32_t upper_only = c->dict_shard.empty() ? 1u : 0u;

@@ -39,10 +39,16 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const KeyT *__restrict__
     s_h[threadIdx.x] = 0;
     __syncthreads();
     const uint64_t base = (uint64_t) blockIdx.x * RS_TILE;
+    KeyT key[RS_ROUNDS];
+#pragma unroll
+    for (int j = 0; j < RS_ROUNDS; j++) {            // all sixteen loads in flight before the first LDS atomic
+        const uint64_t i = base + (uint64_t) j * RS_THREADS + threadIdx.x;
+        key[j] = keys[i < n ? i : n - 1];
+    }
 #pragma unroll
     for (int j = 0; j < RS_ROUNDS; j++) {
         const uint64_t i = base + (uint64_t) j * RS_THREADS + threadIdx.x;
-        if (i < n) atomicAdd(&s_h[rs_digit(keys[i], shift)], 1u);
+        if (i < n) atomicAdd(&s_h[rs_digit(key[j], shift)], 1u);
     }
     __syncthreads();
     counts[(size_t) threadIdx.x * n_tiles + blockIdx.x] = s_h[threadIdx.x];

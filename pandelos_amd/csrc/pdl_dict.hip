@@ -121,6 +121,7 @@ struct KseqApply {
 // k-mers are independent.  A workgroup covers RANK_TILE consecutive stream slots; two lanes
 // bracket the genes of the tile with a binary search, every lane then searches only that bracket.
 // ------------------------------------------------------------------------------------------------
+constexpr uint32_t RANK_SPAN = 128;     // genes whose offsets a tile stages in LDS (more: global lookups)
 constexpr int RANK_THREADS = 256;
 constexpr int RANK_ITEMS = 4;
 constexpr int RANK_TILE = RANK_THREADS * RANK_ITEMS;
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(RANK_THREADS) void k_rank(const uint8_t *__restrict
                                                        RankParams rp, KeyT *__restrict__ keys, uint32_t *__restrict__ vals) {
     __shared__ uint8_t s_rv[256];
     __shared__ uint32_t s_lo, s_hi;
+    __shared__ uint64_t s_koff[RANK_SPAN + 1], s_off[RANK_SPAN];    // k-mer and residue offsets of the genes this tile touches
     for (int i = threadIdx.x; i < 256; i += RANK_THREADS) s_rv[i] = rp.rank_values[i];
     const uint64_t q0 = (uint64_t) blockIdx.x * RANK_TILE;
     const uint64_t q_last = min(q0 + RANK_TILE, m) - 1;
@@ -147,17 +149,33 @@ __global__ __launch_bounds__(RANK_THREADS) void k_rank(const uint8_t *__restrict
     if (threadIdx.x == 64) s_hi = upper_bound_u64(kmer_off, 0, n_seq + 1, q_last) - 1;
     __syncthreads();
     const uint32_t lo = s_lo, hi = s_hi;
+    const uint32_t span = hi - lo + 1;                          // genes under this tile (uniform)
+    const bool staged = span <= RANK_SPAN;
+    if (staged) {
+        for (uint32_t i = threadIdx.x; i <= span; i += RANK_THREADS) s_koff[i] = kmer_off[lo + i];
+        for (uint32_t i = threadIdx.x; i < span; i += RANK_THREADS) s_off[i] = off[lo + i];
+    }
+    __syncthreads();
     const uint32_t k = rp.k;
-    const uint64_t base = rp.base;
+    const KeyT base = (KeyT) rp.base;                           // the polynomial fits KeyT (checked on the host): KeyT arithmetic
 #pragma unroll
     for (int j = 0; j < RANK_ITEMS; j++) {
         const uint64_t q = q0 + (uint64_t) j * RANK_THREADS + threadIdx.x;
         if (q >= m) break;
-        const uint32_t s = upper_bound_u64(kmer_off, lo, hi + 1, q) - 1;   // kmer_off[s] <= q < kmer_off[s+1]
-        const uint8_t *p = res + off[s] + (q - kmer_off[s]);
-        uint64_t r = 0;
+        uint32_t s;
+        const uint8_t *p;
+        if (staged) {                                           // (uniform) boundaries from LDS: no chain of global loads
+            uint32_t a = 0, b = span;                           // first i in [0, span] with s_koff[i] > q, minus one
+            while (a < b) { const uint32_t mid = (a + b) >> 1; if (s_koff[mid + 1] <= q) a = mid + 1; else b = mid; }
+            s = lo + a;
+            p = res + s_off[a] + (q - s_koff[a]);
+        } else {
+            s = upper_bound_u64(kmer_off, lo, hi + 1, q) - 1;   // kmer_off[s] <= q < kmer_off[s+1]
+            p = res + off[s] + (q - kmer_off[s]);
+        }
+        KeyT r = 0;
         for (uint32_t i = 0; i < k; i++) r = r * base + s_rv[p[i]];
-        keys[q] = (KeyT) r;
+        keys[q] = r;
         vals[q] = s;
     }
 }

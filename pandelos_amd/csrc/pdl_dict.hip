@@ -238,15 +238,21 @@ template <class KeyT> struct RecHead {
 template <class KeyT> struct RecScatter {
     const KeyT *keys; const uint32_t *vals; uint64_t m;
     uint32_t *recpos; uint2 *post; uint8_t *ghead;
-    __device__ void operator()(uint64_t q, uint32_t f, uint32_t prefix) const {
-        if (!f) return;
+    struct Loaded { uint32_t val, run; uint8_t head; };
+    __device__ Loaded load(uint64_t q, uint32_t f) const {
+        if (!f) return Loaded{0u, 0u, 0};
         const KeyT key = keys[q];
         const uint32_t val = vals[q];
+        const bool head = q == 0 || keys[q - 1] != key;
         uint64_t j = q + 1;
         while (j < m && keys[j] == key && vals[j] == val) j++;
+        return Loaded{val, (uint32_t) (j - q), (uint8_t) (head ? 1 : 0)};
+    }
+    __device__ void store(uint64_t q, uint32_t f, uint32_t prefix, const Loaded &v) const {
+        if (!f) return;
         recpos[prefix] = (uint32_t) q;
-        post[prefix] = make_uint2(val, (uint32_t) (j - q));
-        ghead[prefix] = (q == 0 || keys[q - 1] != key) ? 1 : 0;
+        post[prefix] = make_uint2(v.val, v.run);
+        ghead[prefix] = v.head;
     }
 };
 
@@ -352,17 +358,19 @@ struct SharedScatter {
     uint32_t *key2; uint4 *tuples;
     uint32_t upper_only;       // 1: a gene's range covers only the postings AFTER its own record (genes above it)
     unsigned long long *cost;  // upper_only: the group size of a group's last member is added here (it has no range)
-    __device__ void operator()(uint64_t u, uint32_t f, uint32_t prefix) const {
+    struct Loaded { uint32_t gs, ge; uint2 po; };
+    __device__ Loaded load(uint64_t u, uint32_t) const {
         const uint32_t g = gid[u];
-        const uint32_t gs = goff[g], ge = goff[g + 1];
+        return Loaded{goff[g], goff[g + 1], post[u]};
+    }
+    __device__ void store(uint64_t u, uint32_t f, uint32_t prefix, const Loaded &v) const {
         if (!f) {
-            if (upper_only && ge - gs >= 2 && (uint32_t) u + 1 == ge) atomicAdd(&cost[post[u].x], (unsigned long long) (ge - gs));
+            if (upper_only && v.ge - v.gs >= 2 && (uint32_t) u + 1 == v.ge) atomicAdd(&cost[v.po.x], (unsigned long long) (v.ge - v.gs));
             return;
         }
-        const uint2 po = post[u];
-        const uint32_t start = upper_only ? (uint32_t) u + 1 : gs;
-        key2[prefix] = po.x;             // (the sort's values are the positions themselves)
-        tuples[prefix] = make_uint4(start, ge - start, po.y, ge - gs);      // {first posting, postings, own count, group size}
+        const uint32_t start = upper_only ? (uint32_t) u + 1 : v.gs;
+        key2[prefix] = v.po.x;             // (the sort's values are the positions themselves)
+        tuples[prefix] = make_uint4(start, v.ge - start, v.po.y, v.ge - v.gs);      // {first posting, postings, own count, group size}
     }
 };
 // Also adds up total_visited (library.cpp:327) = the group sizes over a gene's ranges: the list is gene-sorted, so a

@@ -15,6 +15,12 @@
 
 #include "pdl_common.h"
 
+#include <type_traits>
+
+// an apply functor with a nested type Loaded follows the two-phase protocol (see k_scan_apply)
+template <class T, class = void> struct scan_two_phase : std::false_type {};
+template <class T> struct scan_two_phase<T, std::void_t<typename T::Loaded>> : std::true_type {};
+
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 8;
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;   // 2048
@@ -107,11 +113,30 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(FlagF flag, ApplyF 
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; j++) { s_pref[threadIdx.x * SCAN_ITEMS + j] = prefix; prefix += f[j]; }
     __syncthreads();
+    if constexpr (scan_two_phase<ApplyF>::value) {
+        // the functor splits into load(i, flag) -> Loaded and store(i, flag, prefix, Loaded): every load of the tile's
+        // items is issued before the first store, so the items' dependent load chains overlap (behind a store the
+        // compiler must assume aliasing and would run the items one after the other)
+        typename ApplyF::Loaded v[SCAN_ITEMS];
 #pragma unroll
-    for (int j = 0; j < SCAN_ITEMS; j++) {           // apply in the same coalesced order the flags were read in
-        uint32_t li = j * SCAN_THREADS + threadIdx.x;
-        uint64_t i = base + li;
-        if (i < n) apply(i, s_flags[li], s_pref[li]);
+        for (int j = 0; j < SCAN_ITEMS; j++) {
+            const uint32_t li = j * SCAN_THREADS + threadIdx.x;
+            const uint64_t i = base + li;
+            v[j] = apply.load(i < n ? i : n - 1, s_flags[li]);
+        }
+#pragma unroll
+        for (int j = 0; j < SCAN_ITEMS; j++) {
+            const uint32_t li = j * SCAN_THREADS + threadIdx.x;
+            const uint64_t i = base + li;
+            if (i < n) apply.store(i, s_flags[li], s_pref[li], v[j]);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < SCAN_ITEMS; j++) {       // apply in the same coalesced order the flags were read in
+            uint32_t li = j * SCAN_THREADS + threadIdx.x;
+            uint64_t i = base + li;
+            if (i < n) apply(i, s_flags[li], s_pref[li]);
+        }
     }
 }
 

@@ -16,6 +16,9 @@
 
 #define PDL_WAVE 64
 
+// layout of the control block (pdl_ctx::scalars, u64 words): scalars | residue histogram | per-genome cost
+constexpr size_t PDL_CTL_HIST = 16, PDL_CTL_GCOST = 16 + 256;
+
 // ---- error plumbing -------------------------------------------------------------------------
 struct pdl_error {
     int code;

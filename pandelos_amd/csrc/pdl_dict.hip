@@ -109,9 +109,11 @@ struct KseqFlag {
 };
 struct KseqApply {
     uint32_t *kseq_len; uint64_t *kmer_off;   // kmer_off as u64 for the API; values < 2^32 (checked on the host)
+    unsigned long long *cost;                 // total_visited starts at zero (spares a fill)
     __device__ void operator()(uint64_t i, uint32_t f, uint32_t prefix) const {
         kseq_len[i] = f;
         kmer_off[i] = prefix;
+        cost[i] = 0;
     }
 };
 
@@ -438,7 +440,7 @@ __global__ __launch_bounds__(256) void k_genome_cost(const unsigned long long *_
         csum += __shfl_down(csum, d, PDL_WAVE);
     }
     const uint32_t lane = threadIdx.x & (PDL_WAVE - 1);
-    if (lane == 0 && ksum) { atomicAdd(sum_kseq, ksum); atomicMax(max_kseq, kmax); atomicMin(min_kseq, kmin); }
+    if (lane == 0 && ksum) { atomicAdd(sum_kseq, ksum); atomicMax(max_kseq, kmax); atomicMax(min_kseq, ~kmin); }   // min kept as a max of complements: zero-initialised like the rest
     if (uniform) {
         if (lane == 0 && csum && g0 != 0xffffffffu) atomicAdd(&genome_cost[g0], csum);
     } else if (live && c) {
@@ -453,9 +455,8 @@ static void dictionary_pipeline(pdl_ctx *c, bool only_complexity) {
     const uint64_t M = c->M;
     uint64_t *d_scal = c->scalars.as<uint64_t>();
 
-    PDL_HIP(hipMemsetAsync(d_scal + 3, 0, 2 * sizeof(uint64_t), st));   // (unused), sum of kseq_lengths
-    PDL_HIP(hipMemsetAsync(d_scal + 7, 0, sizeof(uint64_t), st));       // max kseq_length
-    PDL_HIP(hipMemsetAsync(d_scal + 8, 0xff, sizeof(uint64_t), st));    // min non-zero kseq_length
+    // (the control block — scalars, histogram, per-genome costs — was zeroed in one go by pdl_run_preprocess:
+    //  3-4 sum of kseq_lengths, 7 max kseq_length, 8 complement of the min non-zero kseq_length)
 
     // K-rank
     ev_begin(c, EV_RANK);
@@ -509,10 +510,7 @@ static void dictionary_pipeline(pdl_ctx *c, bool only_complexity) {
     PDL_HIP(hipGetLastError());
     ev_end(c, EV_DICT);
 
-    c->cost.alloc((size_t) c->N * sizeof(uint64_t));
-    if (only_complexity) {
-        PDL_HIP(hipMemsetAsync(c->cost.p, 0, (size_t) c->N * sizeof(uint64_t), st));
-        PDL_HIP(hipMemsetAsync(d_scal + 2, 0, sizeof(uint64_t), st));
+    if (only_complexity) {                   // (cost[] was zeroed by K-len's apply, d_scal[2] with the control block)
         hipLaunchKernelGGL(k_record_costs, dim3(ublocks), dim3(256), 0, st, c->post.as<uint2>(), c->gid.as<uint32_t>(),
                            c->goff.as<uint32_t>(), Uu, c->cost.as<unsigned long long>(),
                            reinterpret_cast<unsigned long long *>(d_scal + 2));
@@ -538,7 +536,6 @@ static void dictionary_pipeline(pdl_ctx *c, bool only_complexity) {
             in_shard = c->seq_in_shard.as<uint8_t>();
         }
         const uint32_t upper_only = c->dict_shard.empty() ? 1u : 0u;
-        PDL_HIP(hipMemsetAsync(c->cost.p, 0, (size_t) c->N * sizeof(uint64_t), st));
         scan_and_apply(c, U, SharedFlag{c->gid.as<uint32_t>(), c->goff.as<uint32_t>(), c->post.as<uint2>(), in_shard, upper_only},
                        SharedScatter{c->post.as<uint2>(), c->gid.as<uint32_t>(), c->goff.as<uint32_t>(), k2a, tuples,
                                      upper_only, c->cost.as<unsigned long long>()}, d_scal + 2);
@@ -560,20 +557,18 @@ static void dictionary_pipeline(pdl_ctx *c, bool only_complexity) {
     }
 
     // K-cost
-    c->genome_cost.alloc((size_t) c->G * sizeof(uint64_t));
-    PDL_HIP(hipMemsetAsync(c->genome_cost.p, 0, (size_t) c->G * sizeof(uint64_t), st));
+    unsigned long long *d_gcost = reinterpret_cast<unsigned long long *>(d_scal + PDL_CTL_GCOST);
     hipLaunchKernelGGL(k_genome_cost, dim3((c->N + 255) / 256), dim3(256), 0, st, c->cost.as<unsigned long long>(),
-                       c->kseq_len.as<uint32_t>(), c->d_gen, c->N, c->genome_cost.as<unsigned long long>(),
+                       c->kseq_len.as<uint32_t>(), c->d_gen, c->N, d_gcost,
                        reinterpret_cast<unsigned long long *>(d_scal + 4), reinterpret_cast<unsigned long long *>(d_scal + 7),
                        reinterpret_cast<unsigned long long *>(d_scal + 8));
 
     uint64_t tail[9] = {0};
     {
-        PinRead rd(c);
-        const uint64_t *pg = rd.add<uint64_t>(c->genome_cost.p, c->G);
-        const uint64_t *pt = rd.add<uint64_t>(d_scal, 9);
+        PinRead rd(c);                       // one copy: the whole control block
+        const uint64_t *pt = rd.add<uint64_t>(d_scal, PDL_CTL_GCOST + c->G);
         rd.sync();
-        c->h_genome_cost.assign(pg, pg + c->G);
+        c->h_genome_cost.assign(pt + PDL_CTL_GCOST, pt + PDL_CTL_GCOST + c->G);
         memcpy(tail, pt, sizeof(tail));
     }
     c->Ushared = tail[2];
@@ -581,7 +576,7 @@ static void dictionary_pipeline(pdl_ctx *c, bool only_complexity) {
     c->NG = c->dict_shard.empty() ? tail[1] - (c->U - c->Ushared) : 0;   // (not counted when only a shard's lists are built)
     c->sum_kseq = tail[4];
     c->max_kseq = tail[7];
-    c->min_kseq = tail[8] == ~0ull ? 1 : tail[8];
+    c->min_kseq = tail[8] == 0 ? 1 : ~tail[8];
     c->P = 0;
     for (uint64_t v : c->h_genome_cost) c->P += v;
 }
@@ -590,32 +585,35 @@ void pdl_run_preprocess(pdl_ctx *c, int kvalue, bool only_complexity) {
     hipStream_t st = c->stream;
     if (kvalue <= 0) PDL_FAIL(PDL_ERR_KVALUE, "K value must be greater than 0.");
     ev_begin(c, EV_PRE_TOTAL);
-    c->scalars.alloc(16 * sizeof(uint64_t));
-    c->hist.alloc(256 * sizeof(uint64_t));
+    // control block: scalars[16] | residue histogram[256] | per-genome cost[G] — one allocation, one clearing fill, and
+    // one device->host copy whenever the host looks (every separate small fill or copy is a dispatch of its own)
+    c->scalars.alloc((PDL_CTL_GCOST + (size_t) c->G) * sizeof(uint64_t));
+    uint64_t *d_scal = c->scalars.as<uint64_t>();
+    PDL_HIP(hipMemsetAsync(d_scal, 0, (PDL_CTL_GCOST + (size_t) c->G) * sizeof(uint64_t), st));
 
     // K-hist
     ev_begin(c, EV_HIST);
-    PDL_HIP(hipMemsetAsync(c->hist.p, 0, 256 * sizeof(uint64_t), st));
     if (c->R) {
         uint32_t blocks = (uint32_t) std::min<uint64_t>((c->R / 16 + HIST_THREADS - 1) / HIST_THREADS + 1, 256);
-        hipLaunchKernelGGL(k_hist, dim3(blocks), dim3(HIST_THREADS), 0, st, c->d_res, c->R, c->hist.as<unsigned long long>());
+        hipLaunchKernelGGL(k_hist, dim3(blocks), dim3(HIST_THREADS), 0, st, c->d_res, c->R,
+                           reinterpret_cast<unsigned long long *>(d_scal + PDL_CTL_HIST));
     }
-    // K-len (independent of the histogram)
+    // K-len (independent of the histogram); its apply step also clears cost[], its total also lands in kmer_off[N]
     c->kseq_len.alloc((size_t) c->N * sizeof(uint32_t));
     c->kmer_off.alloc(((size_t) c->N + 1) * sizeof(uint64_t));
-    uint64_t *d_scal = c->scalars.as<uint64_t>();
-    scan_and_apply(c, c->N, KseqFlag{c->d_off, (uint32_t) kvalue}, KseqApply{c->kseq_len.as<uint32_t>(), c->kmer_off.as<uint64_t>()}, d_scal + 5);
-    PDL_HIP(hipMemcpyAsync(c->kmer_off.as<uint64_t>() + c->N, d_scal + 5, sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
+    c->cost.alloc((size_t) c->N * sizeof(uint64_t));
+    scan_and_apply(c, c->N, KseqFlag{c->d_off, (uint32_t) kvalue},
+                   KseqApply{c->kseq_len.as<uint32_t>(), c->kmer_off.as<uint64_t>(), c->cost.as<unsigned long long>()}, d_scal + 5,
+                   c->kmer_off.as<uint64_t>() + c->N);
     uint64_t counters[256];
     uint64_t M = 0;
     {
         PinRead rd(c);
-        const uint64_t *pc = rd.add<uint64_t>(c->hist.p, 256);
-        const uint64_t *pm = rd.add<uint64_t>(d_scal + 5, 1);
+        const uint64_t *pc = rd.add<uint64_t>(d_scal, PDL_CTL_GCOST);          // scalars + histogram in one copy
         ev_end(c, EV_HIST);
         rd.sync();
-        memcpy(counters, pc, sizeof(counters));
-        M = *pm;
+        memcpy(counters, pc + PDL_CTL_HIST, sizeof(counters));
+        M = pc[5];
     }
 
     rank_init_host(c->rp, counters, kvalue);

@@ -859,9 +859,22 @@ struct FinOffApply {
     uint32_t *fin_off;
     __device__ void operator()(uint64_t p, uint32_t, uint32_t prefix) const { fin_off[p] = prefix; }
 };
-__global__ void k_gather_u32(const uint32_t *src, const uint32_t *idx, uint32_t n, uint32_t *dst) {
+// dst[0..n) = src[idx[..]]; then the 8 join counters and the emitted-cell total (u64 as two words) are appended, so the
+// host fetches everything it wants to know after a scoring pass with ONE copy
+__global__ void k_gather_u32(const uint32_t *src, const uint32_t *idx, uint32_t n, uint32_t *dst, const uint32_t *ctr, const uint32_t *z64) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[idx[i]];
+    else if (i < n + 8) dst[i] = ctr[i - n];
+    else if (i < n + 10) dst[i] = z64[i - n - 8];
+}
+
+// Clears up to four arrays in one launch (16-byte words; every separate small fill is a dispatch of its own).
+struct ZeroRanges { uint4 *p[4]; unsigned long long n16[4]; };
+__global__ __launch_bounds__(256) void k_zero_ranges(ZeroRanges z) {
+    const unsigned long long stride = (unsigned long long) gridDim.x * 256;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        for (unsigned long long i = (unsigned long long) blockIdx.x * 256 + threadIdx.x; i < z.n16[r]; i += stride) z.p[r][i] = make_uint4(0, 0, 0, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -899,7 +912,7 @@ void pdl_prepare_tasks(pdl_ctx *c) {
         c->taskpos_of.alloc((size_t) N * 4);
         PDL_HIP(hipMemcpyAsync(c->taskpos_of.p, c->h_taskpos_host.data(), (size_t) N * 4, hipMemcpyHostToDevice, st));
     }
-    c->scratch2.alloc((size_t) (S + 1) * 8);
+    c->scratch2.alloc((size_t) (S + 1) * 8 + 64);      // task offsets | gathered cell offsets + 8 counters + cell total
     PDL_HIP(hipMemcpyAsync(c->scratch2.p, c->h_task_row_off.data(), (size_t) (S + 1) * 4, hipMemcpyHostToDevice, st));
 }
 
@@ -930,14 +943,14 @@ void pdl_run_score_all(pdl_ctx *c) {
     if (mirror && (c->shard_set && S != G))
         PDL_FAIL(PDL_ERR_STATE, "the dictionary was built for all genomes (upper-triangle ranges); a genome shard must be set before pdl_preprocess");
 
-    c->MS.alloc((size_t) n_rows * G * sizeof(float));
-    c->CM.alloc((size_t) S * N * sizeof(float));
+    c->MS.alloc((size_t) n_rows * G * sizeof(float) + 16);      // (+16: cleared in whole 16-byte words)
+    c->CM.alloc((size_t) S * N * sizeof(float) + 16);
     c->row_base.alloc((size_t) n_rows * 4); c->row_cnt.alloc((size_t) n_rows * 4); c->fin_off.alloc(((size_t) n_rows + 1) * 4);
     c->join_ctr.alloc(64);
     c->row_desc.alloc((size_t) n_rows * sizeof(uint4));
     c->row_desc2.alloc((size_t) n_rows * sizeof(uint4));
     c->overflow_rows.alloc((size_t) n_rows * 4 * 2);     // list A (tier 1 -> 2) and list B (tier 2 -> 3)
-    if (mirror) c->mirror_cnt.alloc((size_t) n_rows * 4 * 3);    // counts | offsets | cursors
+    if (mirror) c->mirror_cnt.alloc((size_t) n_rows * 4 * 3 + 16);    // counts | offsets | cursors
     hipLaunchKernelGGL(k_row_desc, dim3((n_rows + 255) / 256), dim3(256), 0, st, c->task_rows.as<uint32_t>(), c->seq_off.as<uint32_t>(),
                        n_rows, c->row_desc.as<uint4>());
 
@@ -1001,11 +1014,17 @@ void pdl_run_score_all(pdl_ctx *c) {
         if (mirror) {
             c->st_src.alloc(cap * 4);
             c->mirror_ref.alloc(cap * 4);
-            PDL_HIP(hipMemsetAsync(c->mirror_cnt.p, 0, (size_t) n_rows * 4 * 3, st));
         }
-        PDL_HIP(hipMemsetAsync(c->MS.p, 0, (size_t) n_rows * G * sizeof(float), st));
-        PDL_HIP(hipMemsetAsync(c->CM.p, 0, (size_t) S * N * sizeof(float), st));
-        PDL_HIP(hipMemsetAsync(c->join_ctr.p, 0, 64, st));
+        {   // maxima, counters and (mirror mode) the per-row mirror counts/offsets/cursors start at zero: one launch
+            auto n16 = [](size_t bytes) { return (unsigned long long) ((bytes + 15) / 16); };      // (buffers are sized in whole 16-byte words)
+            ZeroRanges z{};
+            z.p[0] = c->MS.as<uint4>(); z.n16[0] = n16((size_t) n_rows * G * sizeof(float));
+            z.p[1] = c->CM.as<uint4>(); z.n16[1] = n16((size_t) S * N * sizeof(float));
+            z.p[2] = c->join_ctr.as<uint4>(); z.n16[2] = n16(64);
+            z.p[3] = mirror ? c->mirror_cnt.as<uint4>() : nullptr; z.n16[3] = mirror ? n16((size_t) n_rows * 4 * 3) : 0;
+            const unsigned long long most = std::max(z.n16[0], z.n16[1]);
+            hipLaunchKernelGGL(k_zero_ranges, dim3((uint32_t) std::min<unsigned long long>((most + 255) / 256 + 1, (unsigned long long) cus * 16)), dim3(256), 0, st, z);
+        }
 
         JoinArgs a{};
         a.post = c->post.as<uint2>(); a.ranges = c->ranges.as<uint4>(); a.seq_off = c->seq_off.as<uint32_t>();
@@ -1092,20 +1111,19 @@ void pdl_run_score_all(pdl_ctx *c) {
         // first cell of every shard genome = fin_off at its first task row; then the one look at the counters
         uint32_t *d_idx = c->scratch2.as<uint32_t>();
         uint32_t *d_out = d_idx + (S + 1);
-        hipLaunchKernelGGL(k_gather_u32, dim3((S + 1 + 255) / 256), dim3(256), 0, st, c->fin_off.as<uint32_t>(), d_idx, S + 1, d_out);
+        hipLaunchKernelGGL(k_gather_u32, dim3((S + 1 + 10 + 255) / 256), dim3(256), 0, st, c->fin_off.as<uint32_t>(), d_idx, S + 1, d_out,
+                           c->join_ctr.as<uint32_t>(), reinterpret_cast<const uint32_t *>(d_scal + 6));
         c->h_fin.resize(S + 1);
         uint32_t h_ctr[8];
         uint64_t zsum = 0;
         {
             PinRead rd(c);
-            const uint32_t *pf = rd.add<uint32_t>(d_out, S + 1);
-            const uint32_t *pc = rd.add<uint32_t>(c->join_ctr.p, 8);
-            const uint64_t *pz = rd.add<uint64_t>(d_scal + 6, 1);
+            const uint32_t *pf = rd.add<uint32_t>(d_out, S + 1 + 10);
             ev_end(c, EV_SCORE_TOTAL);
             rd.sync();
             memcpy(c->h_fin.data(), pf, (size_t) (S + 1) * 4);
-            memcpy(h_ctr, pc, sizeof(h_ctr));
-            zsum = *pz;
+            memcpy(h_ctr, pf + S + 1, sizeof(h_ctr));
+            memcpy(&zsum, pf + S + 1 + 8, sizeof(zsum));
         }
         c->glb_clean = true;
         c->tm.overflow_rows = h_ctr[3];

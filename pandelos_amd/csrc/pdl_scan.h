@@ -72,7 +72,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tile_sums(FlagF flag, uin
 }
 
 // one workgroup of 1024 threads; tile_sums becomes its own exclusive scan
-static __global__ __launch_bounds__(1024) void k_scan_tile_scan(uint32_t *tile_sums, uint32_t n_tiles, uint64_t *d_total) {
+static __global__ __launch_bounds__(1024) void k_scan_tile_scan(uint32_t *tile_sums, uint32_t n_tiles, uint64_t *d_total, uint64_t *d_total2) {
     __shared__ uint32_t s_wave[17];
     __shared__ uint32_t s_carry;
     if (threadIdx.x == 0) s_carry = 0;
@@ -88,7 +88,7 @@ static __global__ __launch_bounds__(1024) void k_scan_tile_scan(uint32_t *tile_s
         if (threadIdx.x == 0) s_carry = carry + total;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *d_total = s_carry;
+    if (threadIdx.x == 0) { *d_total = s_carry; if (d_total2) *d_total2 = s_carry; }
 }
 
 template <class FlagF, class ApplyF>
@@ -142,9 +142,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(FlagF flag, ApplyF 
 
 // Host wrapper.  d_total receives the grand total (u64).  scan_tmp is grown as needed.
 template <class FlagF, class ApplyF>
-inline void scan_and_apply(pdl_ctx *c, uint64_t n, FlagF flag, ApplyF apply, uint64_t *d_total) {
+inline void scan_and_apply(pdl_ctx *c, uint64_t n, FlagF flag, ApplyF apply, uint64_t *d_total, uint64_t *d_total2 = nullptr) {
     if (n == 0) {
         PDL_HIP(hipMemsetAsync(d_total, 0, sizeof(uint64_t), c->stream));
+        if (d_total2) PDL_HIP(hipMemsetAsync(d_total2, 0, sizeof(uint64_t), c->stream));
         return;
     }
     const uint64_t tiles64 = (n + SCAN_TILE - 1) / SCAN_TILE;
@@ -153,7 +154,7 @@ inline void scan_and_apply(pdl_ctx *c, uint64_t n, FlagF flag, ApplyF apply, uin
     c->scan_tmp.alloc((size_t) tiles * sizeof(uint32_t));
     uint32_t *ts = c->scan_tmp.as<uint32_t>();
     hipLaunchKernelGGL((k_scan_tile_sums<FlagF>), dim3(tiles), dim3(SCAN_THREADS), 0, c->stream, flag, n, ts);
-    hipLaunchKernelGGL(k_scan_tile_scan, dim3(1), dim3(1024), 0, c->stream, ts, tiles, d_total);
+    hipLaunchKernelGGL(k_scan_tile_scan, dim3(1), dim3(1024), 0, c->stream, ts, tiles, d_total, d_total2);
     hipLaunchKernelGGL((k_scan_apply<FlagF, ApplyF>), dim3(tiles), dim3(SCAN_THREADS), 0, c->stream, flag, apply, n, ts);
     PDL_HIP(hipGetLastError());
 }

@@ -266,13 +266,13 @@ struct GroupHeadFlag {
     __device__ uint32_t operator()(uint64_t u) const { return (u_count >= 2 && u == u_count - 1) ? 0u : ghead[u]; }
 };
 struct GroupScatter {
-    uint32_t *gid; uint32_t *goff;
+    uint32_t *gid; uint32_t *goff; uint64_t u_count;
     __device__ void operator()(uint64_t u, uint32_t f, uint32_t prefix) const {
         gid[u] = prefix + f - 1;           // inclusive count - 1
         if (f) goff[prefix] = (uint32_t) u;
+        if (u == u_count - 1) goff[prefix + f] = (uint32_t) u_count;      // closes the offsets: goff[number of groups] = U
     }
 };
-__global__ void k_close_offsets(uint32_t *goff, const uint64_t *d_ng, uint32_t u_count) { goff[*d_ng] = u_count; }
 
 // The reference re-sorts every shared group by gene (library.cpp:312-315).  After the stable sort all groups
 // already are in gene order except the last one when the globally last record was folded into it (:300-306):
@@ -503,8 +503,7 @@ static void dictionary_pipeline(pdl_ctx *c, bool only_complexity) {
     c->gid.alloc(U * sizeof(uint32_t));
     c->goff.alloc((U + 2) * sizeof(uint32_t));
     // K-groups
-    scan_and_apply(c, U, GroupHeadFlag{ghead, U}, GroupScatter{c->gid.as<uint32_t>(), c->goff.as<uint32_t>()}, d_scal + 1);
-    hipLaunchKernelGGL(k_close_offsets, dim3(1), dim3(1), 0, st, c->goff.as<uint32_t>(), d_scal + 1, Uu);
+    scan_and_apply(c, U, GroupHeadFlag{ghead, U}, GroupScatter{c->gid.as<uint32_t>(), c->goff.as<uint32_t>(), U}, d_scal + 1);
     hipLaunchKernelGGL(k_fold_last_record, dim3(1), dim3(1024), 0, st, c->post.as<uint2>(), c->recpos.as<uint32_t>(), c->goff.as<uint32_t>(),
                        d_scal + 1, Uu);
     PDL_HIP(hipGetLastError());

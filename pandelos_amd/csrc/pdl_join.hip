@@ -916,7 +916,6 @@ void pdl_prepare_tasks(pdl_ctx *c) {
     PDL_HIP(hipMemcpyAsync(c->scratch2.p, c->h_task_row_off.data(), (size_t) (S + 1) * 4, hipMemcpyHostToDevice, st));
 }
 
-__global__ void k_set_u32_from_u64(uint32_t *dst, const uint64_t *src) { *dst = (uint32_t) *src; }
 __global__ void k_iota_u32(uint32_t *dst, uint32_t n) { uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) dst[i] = i; }
 
 void pdl_run_score_all(pdl_ctx *c) {
@@ -945,7 +944,7 @@ void pdl_run_score_all(pdl_ctx *c) {
 
     c->MS.alloc((size_t) n_rows * G * sizeof(float) + 16);      // (+16: cleared in whole 16-byte words)
     c->CM.alloc((size_t) S * N * sizeof(float) + 16);
-    c->row_base.alloc((size_t) n_rows * 4); c->row_cnt.alloc((size_t) n_rows * 4); c->fin_off.alloc(((size_t) n_rows + 1) * 4);
+    c->row_base.alloc((size_t) n_rows * 4); c->row_cnt.alloc((size_t) n_rows * 4); c->fin_off.alloc(((size_t) n_rows + 2) * 4);      // (+1: the scan stores its 64-bit total at [n_rows])
     c->join_ctr.alloc(64);
     c->row_desc.alloc((size_t) n_rows * sizeof(uint4));
     c->row_desc2.alloc((size_t) n_rows * sizeof(uint4));
@@ -1086,8 +1085,9 @@ void pdl_run_score_all(pdl_ctx *c) {
         // ---- order ----------------------------------------------------------------------------------
         ev_begin(c, EV_ORDER);
         const uint32_t *d_mcnt = mirror ? c->mirror_cnt.as<uint32_t>() : nullptr;
-        scan_and_apply(c, n_rows, RowCntFlag{c->row_cnt.as<uint32_t>(), d_mcnt}, FinOffApply{c->fin_off.as<uint32_t>()}, d_scal + 6);
-        hipLaunchKernelGGL(k_set_u32_from_u64, dim3(1), dim3(1), 0, st, c->fin_off.as<uint32_t>() + n_rows, d_scal + 6);
+        // the scan's total (all emitted cells, < 2^32) also closes fin_off: the low word of the u64 lands in fin_off[n_rows]
+        scan_and_apply(c, n_rows, RowCntFlag{c->row_cnt.as<uint32_t>(), d_mcnt}, FinOffApply{c->fin_off.as<uint32_t>()}, d_scal + 6,
+                       reinterpret_cast<uint64_t *>(c->fin_off.as<uint32_t>() + n_rows));
         OrderArgs o{};
         if (mirror) {
             uint32_t *m_off = c->mirror_cnt.as<uint32_t>() + n_rows, *m_cur = m_off + n_rows;

@@ -88,7 +88,13 @@ static __global__ __launch_bounds__(1024) void k_scan_tile_scan(uint32_t *tile_s
         if (threadIdx.x == 0) s_carry = carry + total;
         __syncthreads();
     }
-    if (threadIdx.x == 0) { *d_total = s_carry; if (d_total2) *d_total2 = s_carry; }
+    if (threadIdx.x == 0) {
+        *d_total = s_carry;
+        if (d_total2) {                      // second copy of the total, as two words: its address may be only 4-byte aligned
+            reinterpret_cast<uint32_t *>(d_total2)[0] = s_carry;
+            reinterpret_cast<uint32_t *>(d_total2)[1] = 0u;
+        }
+    }
 }
 
 template <class FlagF, class ApplyF>

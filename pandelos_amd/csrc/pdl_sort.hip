@@ -85,12 +85,27 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const KeyT *__restric
     uint32_t val[RS_ROUNDS];
     uint16_t rank[RS_ROUNDS];          // position among the wave's elements of the same digit
     const unsigned long long below = (1ull << lane) - 1ull;
+    // every load of the tile first, branch-free (clamped index): thirty-two loads in flight per lane.  Behind a branch or
+    // an LDS store the compiler keeps program order and would wait for each round's load before ranking it.
+#pragma unroll
+    for (int j = 0; j < RS_ROUNDS; j++) {
+        const uint64_t i = wave_base + (uint64_t) j * PDL_WAVE + lane;
+        key[j] = keys_in[i < n ? i : n - 1];
+    }
+    if (vals_in) {                                   // uniform
+#pragma unroll
+        for (int j = 0; j < RS_ROUNDS; j++) {
+            const uint64_t i = wave_base + (uint64_t) j * PDL_WAVE + lane;
+            val[j] = vals_in[i < n ? i : n - 1];
+        }
+    } else {                                         // the values are the positions 0, 1, 2, ...
+#pragma unroll
+        for (int j = 0; j < RS_ROUNDS; j++) val[j] = (uint32_t) (wave_base + (uint64_t) j * PDL_WAVE + lane);
+    }
 #pragma unroll
     for (int j = 0; j < RS_ROUNDS; j++) {
         const uint64_t i = wave_base + (uint64_t) j * PDL_WAVE + lane;
         const bool valid = i < n;
-        key[j] = valid ? keys_in[i] : (KeyT) 0;
-        val[j] = valid ? (vals_in ? vals_in[i] : (uint32_t) i) : 0u;     // vals_in == nullptr: the values are the positions 0, 1, 2, ...
         const uint32_t d = rs_digit(key[j], shift);
         unsigned long long same = __ballot(valid);
 #pragma unroll

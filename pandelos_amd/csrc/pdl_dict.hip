@@ -137,9 +137,18 @@ __device__ __forceinline__ uint32_t upper_bound_u64(const uint64_t *a, uint32_t 
     return lo;
 }
 
+struct __attribute__((packed, aligned(1))) UnalignedU64 { uint64_t v; };
+// eight residues from byte position p (any alignment); near the end of the buffer byte by byte
+__device__ __forceinline__ uint64_t load_residues8(const uint8_t *__restrict__ res, uint64_t p, uint64_t n_res) {
+    if (p + 8 <= n_res) return reinterpret_cast<const UnalignedU64 *>(res + p)->v;
+    uint64_t w = 0;
+    for (uint32_t b = 0; b < 8 && p + b < n_res; b++) w |= (uint64_t) res[p + b] << (8 * b);
+    return w;
+}
+
 template <class KeyT>
 __global__ __launch_bounds__(RANK_THREADS) void k_rank(const uint8_t *__restrict__ res, const uint64_t *__restrict__ off,
-                                                       const uint64_t *__restrict__ kmer_off, uint32_t n_seq, uint64_t m,
+                                                       const uint64_t *__restrict__ kmer_off, uint32_t n_seq, uint64_t m, uint64_t n_res,
                                                        RankParams rp, KeyT *__restrict__ keys, uint32_t *__restrict__ vals) {
     __shared__ uint8_t s_rv[256];
     __shared__ uint32_t s_lo, s_hi;
@@ -160,25 +169,49 @@ __global__ __launch_bounds__(RANK_THREADS) void k_rank(const uint8_t *__restrict
     __syncthreads();
     const uint32_t k = rp.k;
     const KeyT base = (KeyT) rp.base;                           // the polynomial fits KeyT (checked on the host): KeyT arithmetic
+    // Phase 1: gene and residue position of the lane's four k-mers.  Phase 2: their residues, eight bytes per load, the
+    // loads of the four k-mers in flight together (a byte loop with a wait per byte serialises 4 x k round trips).
+    uint32_t sq[RANK_ITEMS];
+    uint64_t pos[RANK_ITEMS];
+#pragma unroll
+    for (int j = 0; j < RANK_ITEMS; j++) {
+        const uint64_t qj = q0 + (uint64_t) j * RANK_THREADS + threadIdx.x;
+        const uint64_t q = qj < m ? qj : m - 1;
+        if (staged) {                                           // (uniform) boundaries from LDS: no chain of global loads
+            uint32_t a = 0, b = span;                           // last i in [0, span) with s_koff[i] <= q
+            while (a < b) { const uint32_t mid = (a + b) >> 1; if (s_koff[mid + 1] <= q) a = mid + 1; else b = mid; }
+            sq[j] = lo + a;
+            pos[j] = s_off[a] + (q - s_koff[a]);
+        } else {
+            sq[j] = upper_bound_u64(kmer_off, lo, hi + 1, q) - 1;   // kmer_off[s] <= q < kmer_off[s+1]
+            pos[j] = off[sq[j]] + (q - kmer_off[sq[j]]);
+        }
+    }
+    KeyT r[RANK_ITEMS];
+#pragma unroll
+    for (int j = 0; j < RANK_ITEMS; j++) r[j] = 0;
+    for (uint32_t c0 = 0; c0 < k; c0 += 8) {
+        uint64_t w[RANK_ITEMS];
+        bool safe = true;
+#pragma unroll
+        for (int j = 0; j < RANK_ITEMS; j++) safe = safe && pos[j] + c0 + 8 <= n_res;
+        if (__all(safe)) {                                      // (every tile but the last): four unaligned 8-byte loads, no branches between them
+#pragma unroll
+            for (int j = 0; j < RANK_ITEMS; j++) w[j] = reinterpret_cast<const UnalignedU64 *>(res + pos[j] + c0)->v;
+        } else {
+#pragma unroll
+            for (int j = 0; j < RANK_ITEMS; j++) w[j] = load_residues8(res, pos[j] + c0, n_res);
+        }
+        const uint32_t nb = min(8u, k - c0);
+        for (uint32_t b = 0; b < nb; b++) {
+#pragma unroll
+            for (int j = 0; j < RANK_ITEMS; j++) r[j] = r[j] * base + s_rv[(uint32_t) (w[j] >> (8 * b)) & 0xffu];
+        }
+    }
 #pragma unroll
     for (int j = 0; j < RANK_ITEMS; j++) {
         const uint64_t q = q0 + (uint64_t) j * RANK_THREADS + threadIdx.x;
-        if (q >= m) break;
-        uint32_t s;
-        const uint8_t *p;
-        if (staged) {                                           // (uniform) boundaries from LDS: no chain of global loads
-            uint32_t a = 0, b = span;                           // first i in [0, span] with s_koff[i] > q, minus one
-            while (a < b) { const uint32_t mid = (a + b) >> 1; if (s_koff[mid + 1] <= q) a = mid + 1; else b = mid; }
-            s = lo + a;
-            p = res + s_off[a] + (q - s_koff[a]);
-        } else {
-            s = upper_bound_u64(kmer_off, lo, hi + 1, q) - 1;   // kmer_off[s] <= q < kmer_off[s+1]
-            p = res + off[s] + (q - kmer_off[s]);
-        }
-        KeyT r = 0;
-        for (uint32_t i = 0; i < k; i++) r = r * base + s_rv[p[i]];
-        keys[q] = r;
-        vals[q] = s;
+        if (q < m) { keys[q] = r[j]; vals[q] = sq[j]; }
     }
 }
 
@@ -472,7 +505,7 @@ static void dictionary_pipeline(pdl_ctx *c, bool only_complexity) {
     } else {
         const uint64_t tiles = (M + RANK_TILE - 1) / RANK_TILE;
         hipLaunchKernelGGL((k_rank<KeyT>), dim3((uint32_t) tiles), dim3(RANK_THREADS), 0, st, c->d_res, c->d_off,
-                           c->kmer_off.as<uint64_t>(), c->N, M, c->rp, keys_in, vals_in);
+                           c->kmer_off.as<uint64_t>(), c->N, M, c->R, c->rp, keys_in, vals_in);
     }
     PDL_HIP(hipGetLastError());
     ev_end(c, EV_RANK);

@@ -263,8 +263,11 @@ __global__ __launch_bounds__(256) void k_rank_hash(const uint8_t *__restrict__ r
 // ------------------------------------------------------------------------------------------------
 template <class KeyT> struct RecHead {
     const KeyT *keys; const uint32_t *vals;
-    __device__ uint32_t operator()(uint64_t q) const {
-        return (q == 0 || keys[q] != keys[q - 1] || vals[q] != vals[q - 1]) ? 1u : 0u;
+    __device__ uint32_t operator()(uint64_t q) const {     // straight-line (no short-circuit): the loads of a thread's items overlap
+        const uint64_t qp = q ? q - 1 : 0;
+        const KeyT k0 = keys[q], k1 = keys[qp];
+        const uint32_t v0 = vals[q], v1 = vals[qp];
+        return (uint32_t) (q == 0) | (uint32_t) (k0 != k1) | (uint32_t) (v0 != v1);
     }
 };
 // The apply side also builds the record: post[u] = {gene, run length}, ghead[u] = 1 when record u opens a rank-group
@@ -376,16 +379,15 @@ __global__ __launch_bounds__(256) void k_record_costs(const uint2 *__restrict__ 
 //   3. one gather of the 16-byte tuples through the sorted indices          [one random 16 B read each]
 // (Slot allocation with global atomics was measured 4x slower than the sort: device-scope atomics on
 // scattered counters run at the memory side on this chip.)
-struct SharedFlag {
+template <bool UPPER_ONLY> struct SharedFlag {         // the mode is a template parameter: the per-item code stays straight-line
     const uint32_t *gid; const uint32_t *goff;
-    const uint2 *post; const uint8_t *in_shard;      // in_shard == nullptr: every gene gets a range list
-    uint32_t upper_only;                             // 1: the last member of a group has nothing above it: no range
+    const uint2 *post; const uint8_t *in_shard;      // !UPPER_ONLY: only the genes of the shard get range lists
     __device__ uint32_t operator()(uint64_t u) const {
         const uint32_t g = gid[u];
-        const uint32_t ge = goff[g + 1];
-        if ((ge - goff[g]) < 2) return 0u;
-        if (upper_only) return (uint32_t) u + 1 < ge ? 1u : 0u;
-        return in_shard ? (uint32_t) in_shard[post[u].x] : 1u;
+        const uint32_t gs = goff[g], ge = goff[g + 1];
+        const uint32_t shared = (uint32_t) (ge - gs >= 2);
+        if constexpr (UPPER_ONLY) return shared & (uint32_t) ((uint32_t) u + 1 < ge);   // the last member of a group has nothing above it
+        else return shared & (uint32_t) in_shard[post[u].x];
     }
 };
 struct SharedScatter {
@@ -568,9 +570,10 @@ static void dictionary_pipeline(pdl_ctx *c, bool only_complexity) {
             in_shard = c->seq_in_shard.as<uint8_t>();
         }
         const uint32_t upper_only = c->dict_shard.empty() ? 1u : 0u;
-        scan_and_apply(c, U, SharedFlag{c->gid.as<uint32_t>(), c->goff.as<uint32_t>(), c->post.as<uint2>(), in_shard, upper_only},
-                       SharedScatter{c->post.as<uint2>(), c->gid.as<uint32_t>(), c->goff.as<uint32_t>(), k2a, tuples,
-                                     upper_only, c->cost.as<unsigned long long>()}, d_scal + 2);
+        const SharedScatter scatter{c->post.as<uint2>(), c->gid.as<uint32_t>(), c->goff.as<uint32_t>(), k2a, tuples,
+                                    upper_only, c->cost.as<unsigned long long>()};
+        if (upper_only) scan_and_apply(c, U, SharedFlag<true>{c->gid.as<uint32_t>(), c->goff.as<uint32_t>(), c->post.as<uint2>(), nullptr}, scatter, d_scal + 2);
+        else scan_and_apply(c, U, SharedFlag<false>{c->gid.as<uint32_t>(), c->goff.as<uint32_t>(), c->post.as<uint2>(), in_shard}, scatter, d_scal + 2);
         c->upper_only = upper_only != 0;
         uint64_t Us = 0;
         { PinRead rd(c); const uint64_t *pu = rd.add<uint64_t>(d_scal + 2, 1); rd.sync(); Us = *pu; }

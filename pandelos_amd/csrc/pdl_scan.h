@@ -62,9 +62,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_tile_sums(FlagF flag, uin
     const uint64_t base = (uint64_t) blockIdx.x * SCAN_TILE;
     uint32_t sum = 0;
 #pragma unroll
-    for (int j = 0; j < SCAN_ITEMS; j++) {
-        uint64_t i = base + (uint64_t) j * SCAN_THREADS + threadIdx.x;
-        if (i < n) sum += flag(i);
+    for (int j = 0; j < SCAN_ITEMS; j++) {           // branch-free (index clamped, result masked): the loads of all items overlap
+        const uint64_t i = base + (uint64_t) j * SCAN_THREADS + threadIdx.x;
+        const uint32_t f = flag(i < n ? i : n - 1);
+        sum += i < n ? f : 0u;
     }
     uint32_t total;
     (void) block_exclusive_scan_u32(sum, s_wave, total);
@@ -105,9 +106,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(FlagF flag, ApplyF 
     const uint64_t base = (uint64_t) blockIdx.x * SCAN_TILE;
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; j++) {           // coalesced flag evaluation
-        uint32_t li = j * SCAN_THREADS + threadIdx.x;
-        uint64_t i = base + li;
-        s_flags[li] = i < n ? flag(i) : 0u;
+        const uint32_t li = j * SCAN_THREADS + threadIdx.x;
+        const uint64_t i = base + li;
+        const uint32_t f = flag(i < n ? i : n - 1);
+        s_flags[li] = i < n ? f : 0u;
     }
     __syncthreads();
     uint32_t f[SCAN_ITEMS];

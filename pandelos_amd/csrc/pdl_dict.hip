@@ -277,13 +277,16 @@ template <class KeyT> struct RecScatter {
     const KeyT *keys; const uint32_t *vals; uint64_t m;
     uint32_t *recpos; uint2 *post; uint8_t *ghead;
     struct Loaded { uint32_t val, run; uint8_t head; };
-    __device__ Loaded load(uint64_t q, uint32_t f) const {
-        if (!f) return Loaded{0u, 0u, 0};
-        const KeyT key = keys[q];
-        const uint32_t val = vals[q];
-        const bool head = q == 0 || keys[q - 1] != key;
+    __device__ Loaded load(uint64_t q, uint32_t) const {    // straight-line for the common run of one; the rare longer run loops
+        const uint64_t qp = q ? q - 1 : 0, qn = q + 1 < m ? q + 1 : q;
+        const KeyT key = keys[q], kprev = keys[qp], knext = keys[qn];
+        const uint32_t val = vals[q], vnext = vals[qn];
+        const bool head = q == 0 || kprev != key;
         uint64_t j = q + 1;
-        while (j < m && keys[j] == key && vals[j] == val) j++;
+        if (j < m && knext == key && vnext == val) {
+            j++;
+            while (j < m && keys[j] == key && vals[j] == val) j++;
+        }
         return Loaded{val, (uint32_t) (j - q), (uint8_t) (head ? 1 : 0)};
     }
     __device__ void store(uint64_t q, uint32_t f, uint32_t prefix, const Loaded &v) const {

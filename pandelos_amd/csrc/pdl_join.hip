@@ -208,12 +208,18 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ == 10) ? 5 : 1) void k_join
     // stage ranges [e0 + b0, e0 + b0 + nb) and return the number of lookups they hold
     auto stage = [&](uint32_t e0, uint32_t b0, uint32_t nb) -> uint32_t {
         uint32_t len[RPT], sum = 0;
+        uint4 rgs[RPT];
+#pragma unroll
+        for (uint32_t j = 0; j < RPT; j++) {                 // the loads first, branch-free: they overlap
+            const uint32_t i = tid * RPT + j;
+            rgs[j] = a.ranges[e0 + b0 + (i < nb ? i : nb - 1)];   // {first posting, postings, own count, group size}
+        }
 #pragma unroll
         for (uint32_t j = 0; j < RPT; j++) {
             const uint32_t i = tid * RPT + j;
             len[j] = 0;
             if (i < nb) {
-                const uint4 rg = a.ranges[e0 + b0 + i];       // {group start, length, own count}
+                const uint4 rg = rgs[j];
                 s_gm[i] = make_uint2(rg.x, rg.z); s_gsv[i] = rg.x + rg.y - rg.w; len[j] = rg.y;
             }
             sum += len[j];

@@ -301,14 +301,15 @@ template <class KeyT> struct RecScatter {
 // its rank, i.e. the last record never opens a group: when it is the only record of the largest rank it is folded
 // into the preceding group (and moved to its gene-order place by k_fold_last_record).
 struct GroupHeadFlag {
-    const uint8_t *ghead; uint64_t u_count;
-    __device__ uint32_t operator()(uint64_t u) const { return (u_count >= 2 && u == u_count - 1) ? 0u : ghead[u]; }
+    const uint8_t *ghead; const uint64_t *d_u;       // *d_u = U (the host has not read it back)
+    __device__ uint32_t operator()(uint64_t u) const { const uint64_t u_count = *d_u; return (u_count >= 2 && u == u_count - 1) ? 0u : ghead[u]; }
 };
 struct GroupScatter {
-    uint32_t *gid; uint32_t *goff; uint64_t u_count;
+    uint32_t *gid; uint32_t *goff; const uint64_t *d_u;
     __device__ void operator()(uint64_t u, uint32_t f, uint32_t prefix) const {
         gid[u] = prefix + f - 1;           // inclusive count - 1
         if (f) goff[prefix] = (uint32_t) u;
+        const uint64_t u_count = *d_u;
         if (u == u_count - 1) goff[prefix + f] = (uint32_t) u_count;      // closes the offsets: goff[number of groups] = U
     }
 };
@@ -318,8 +319,9 @@ struct GroupScatter {
 // move that record to its place (insertion into a sorted run).  One workgroup; recpos moves along so that
 // (rank via recpos, gene, count) stay one record.  The join's "columns above the row" trick relies on this order.
 __global__ __launch_bounds__(1024) void k_fold_last_record(uint2 *__restrict__ post, uint32_t *__restrict__ recpos,
-                                                           const uint32_t *__restrict__ goff, const uint64_t *d_ng, uint32_t u_count) {
+                                                           const uint32_t *__restrict__ goff, const uint64_t *d_ng, const uint64_t *d_u) {
     __shared__ uint32_t s_p;
+    const uint32_t u_count = (uint32_t) *d_u;
     if (u_count < 2) return;
     const uint32_t gs = goff[*d_ng - 1];
     const uint32_t lastp = u_count - 1;
@@ -353,10 +355,11 @@ __global__ __launch_bounds__(1024) void k_fold_last_record(uint2 *__restrict__ p
 // total_visited (library.cpp:327) straight from the records: every record of a group with >= 2 records
 // adds the group size to its gene.  Only used in complexity-only mode (no range lists to sum over).
 __global__ __launch_bounds__(256) void k_record_costs(const uint2 *__restrict__ post, const uint32_t *__restrict__ gid,
-                                                      const uint32_t *__restrict__ goff, uint32_t u_count,
+                                                      const uint32_t *__restrict__ goff, const uint64_t *d_u,
                                                       unsigned long long *__restrict__ cost,
                                                       unsigned long long *__restrict__ n_shared_records) {
     __shared__ uint32_t s_cnt;
+    const uint32_t u_count = (uint32_t) *d_u;
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
     const uint32_t u = blockIdx.x * 256 + threadIdx.x;
@@ -416,9 +419,11 @@ struct SharedScatter {
 // Also adds up total_visited (library.cpp:327) = the group sizes over a gene's ranges: the list is gene-sorted, so a
 // wave holds one or two genes as a rule; one atomic per (wave, gene).
 __global__ __launch_bounds__(256) void k_gather_ranges(const uint32_t *__restrict__ idx_sorted, const uint32_t *__restrict__ key_sorted,
-                                                       const uint4 *__restrict__ tuples, uint32_t n, uint4 *__restrict__ ranges,
+                                                       const uint4 *__restrict__ tuples, const uint64_t *d_n, uint4 *__restrict__ ranges,
                                                        unsigned long long *__restrict__ cost) {
+    const uint32_t n = (uint32_t) *d_n;                  // U' (grid sized for the bound M)
     const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x * 256u >= n) return;                  // (uniform)
     const uint32_t lane = threadIdx.x & (PDL_WAVE - 1);
     const bool live = e < n;
     uint32_t g = 0xffffffffu;
@@ -442,8 +447,9 @@ __global__ __launch_bounds__(256) void k_gather_ranges(const uint32_t *__restric
     }
 }
 // seq_off[s] = first range of gene s in the gene-sorted list (lower bound), seq_off[N] = number of ranges
-__global__ __launch_bounds__(256) void k_seq_offsets(const uint32_t *__restrict__ key_sorted, uint32_t n, uint32_t n_seq,
+__global__ __launch_bounds__(256) void k_seq_offsets(const uint32_t *__restrict__ key_sorted, const uint64_t *d_n, uint32_t n_seq,
                                                      uint32_t *__restrict__ seq_off) {
+    const uint32_t n = (uint32_t) *d_n;
     const uint32_t s = blockIdx.x * 256 + threadIdx.x;
     if (s > n_seq) return;
     uint32_t lo = 0, hi = n;
@@ -533,34 +539,33 @@ static void dictionary_pipeline(pdl_ctx *c, bool only_complexity) {
     uint8_t *ghead = reinterpret_cast<uint8_t *>(c->keys_a.p);   // keys_a is free after the sort (>= M bytes)
     scan_and_apply(c, M, RecHead<KeyT>{skeys, svals},
                    RecScatter<KeyT>{skeys, svals, M, c->recpos.as<uint32_t>(), c->post.as<uint2>(), ghead}, d_scal + 0);
-    uint64_t U = 0;
-    { PinRead rd(c); const uint64_t *pu = rd.add<uint64_t>(d_scal + 0, 1); rd.sync(); U = *pu; }
-    c->U = U;
-    const uint32_t Uu = (uint32_t) U;
-    const uint32_t ublocks = (Uu + 255) / 256;
-    c->gid.alloc(U * sizeof(uint32_t));
-    c->goff.alloc((U + 2) * sizeof(uint32_t));
+    // U (records) and U' (shared records) stay on the device until the end of the build: everything below is sized and
+    // launched for the bound M and reads the counts there — no host round trip in the middle of the pipeline
+    const uint64_t *d_u = d_scal + 0;
+    const uint32_t ublocks = (uint32_t) ((M + 255) / 256);
+    c->gid.alloc(M * sizeof(uint32_t));
+    c->goff.alloc((M + 2) * sizeof(uint32_t));
     // K-groups
-    scan_and_apply(c, U, GroupHeadFlag{ghead, U}, GroupScatter{c->gid.as<uint32_t>(), c->goff.as<uint32_t>(), U}, d_scal + 1);
+    scan_and_apply(c, M, GroupHeadFlag{ghead, d_u}, GroupScatter{c->gid.as<uint32_t>(), c->goff.as<uint32_t>(), d_u}, d_scal + 1, nullptr, d_u);
     hipLaunchKernelGGL(k_fold_last_record, dim3(1), dim3(1024), 0, st, c->post.as<uint2>(), c->recpos.as<uint32_t>(), c->goff.as<uint32_t>(),
-                       d_scal + 1, Uu);
+                       d_scal + 1, d_u);
     PDL_HIP(hipGetLastError());
     ev_end(c, EV_DICT);
 
     if (only_complexity) {                   // (cost[] was zeroed by K-len's apply, d_scal[2] with the control block)
         hipLaunchKernelGGL(k_record_costs, dim3(ublocks), dim3(256), 0, st, c->post.as<uint2>(), c->gid.as<uint32_t>(),
-                           c->goff.as<uint32_t>(), Uu, c->cost.as<unsigned long long>(),
+                           c->goff.as<uint32_t>(), d_u, c->cost.as<unsigned long long>(),
                            reinterpret_cast<unsigned long long *>(d_scal + 2));
     } else {
         // K-ranges
         ev_begin(c, EV_SORT2);
-        // scratch layout: tuples uint4[U] | v2a u32[U] | k2b u32[U] | v2b u32[U]; key2 lives in vals_a (free after sort 1)
-        c->scratch.alloc(U * (sizeof(uint4) + 3 * sizeof(uint32_t)));
+        // scratch layout: tuples uint4[M] | v2a u32[M] | k2b u32[M] | v2b u32[M]; key2 lives in vals_a (free after sort 1)
+        c->scratch.alloc(M * (sizeof(uint4) + 3 * sizeof(uint32_t)));
         uint4 *tuples = c->scratch.as<uint4>();
         uint32_t *k2a = c->vals_a.as<uint32_t>();
-        uint32_t *v2a = reinterpret_cast<uint32_t *>(tuples + U);
-        uint32_t *k2b = v2a + U;
-        uint32_t *v2b = k2b + U;
+        uint32_t *v2a = reinterpret_cast<uint32_t *>(tuples + M);
+        uint32_t *k2b = v2a + M;
+        uint32_t *v2b = k2b + M;
         const uint8_t *in_shard = nullptr;
         if (!c->dict_shard.empty()) {       // multi-GPU: only the genes this context scores need range lists
             std::vector<uint8_t> &h = c->h_seq_in_shard;   // lives in the context: the copy below needs no synchronisation
@@ -575,21 +580,19 @@ static void dictionary_pipeline(pdl_ctx *c, bool only_complexity) {
         const uint32_t upper_only = c->dict_shard.empty() ? 1u : 0u;
         const SharedScatter scatter{c->post.as<uint2>(), c->gid.as<uint32_t>(), c->goff.as<uint32_t>(), k2a, tuples,
                                     upper_only, c->cost.as<unsigned long long>()};
-        if (upper_only) scan_and_apply(c, U, SharedFlag<true>{c->gid.as<uint32_t>(), c->goff.as<uint32_t>(), c->post.as<uint2>(), nullptr}, scatter, d_scal + 2);
-        else scan_and_apply(c, U, SharedFlag<false>{c->gid.as<uint32_t>(), c->goff.as<uint32_t>(), c->post.as<uint2>(), in_shard}, scatter, d_scal + 2);
+        const uint64_t *d_us = d_scal + 2;       // U' = the scan's total
+        if (upper_only) scan_and_apply(c, M, SharedFlag<true>{c->gid.as<uint32_t>(), c->goff.as<uint32_t>(), c->post.as<uint2>(), nullptr}, scatter, d_scal + 2, nullptr, d_u);
+        else scan_and_apply(c, M, SharedFlag<false>{c->gid.as<uint32_t>(), c->goff.as<uint32_t>(), c->post.as<uint2>(), in_shard}, scatter, d_scal + 2, nullptr, d_u);
         c->upper_only = upper_only != 0;
-        uint64_t Us = 0;
-        { PinRead rd(c); const uint64_t *pu = rd.add<uint64_t>(d_scal + 2, 1); rd.sync(); Us = *pu; }
         const uint32_t seq_bits = std::max<uint32_t>(1, bit_length64(c->N ? c->N - 1 : 0));
-        pdl_sort_pairs<uint32_t>(c, k2a, k2b, v2a, v2b, Us, seq_bits, true);     // values = tuple positions; sorted pairs now in (k2b, v2b)
+        pdl_sort_pairs<uint32_t>(c, k2a, k2b, v2a, v2b, M, seq_bits, true, d_us);     // values = tuple positions; sorted pairs now in (k2b, v2b)
         ev_end(c, EV_SORT2);
 
         ev_begin(c, EV_RANGES);
-        c->ranges.alloc(std::max<uint64_t>(Us, 1) * sizeof(uint4));
+        c->ranges.alloc(M * sizeof(uint4));
         c->seq_off.alloc(((size_t) c->N + 1) * sizeof(uint32_t));
-        if (Us) hipLaunchKernelGGL(k_gather_ranges, dim3(((uint32_t) Us + 255) / 256), dim3(256), 0, st, v2b, k2b, tuples, (uint32_t) Us,
-                                   c->ranges.as<uint4>(), c->cost.as<unsigned long long>());
-        hipLaunchKernelGGL(k_seq_offsets, dim3((c->N + 1 + 255) / 256), dim3(256), 0, st, k2b, (uint32_t) Us, c->N, c->seq_off.as<uint32_t>());
+        hipLaunchKernelGGL(k_gather_ranges, dim3(ublocks), dim3(256), 0, st, v2b, k2b, tuples, d_us, c->ranges.as<uint4>(), c->cost.as<unsigned long long>());
+        hipLaunchKernelGGL(k_seq_offsets, dim3((c->N + 1 + 255) / 256), dim3(256), 0, st, k2b, d_us, c->N, c->seq_off.as<uint32_t>());
         PDL_HIP(hipGetLastError());
         ev_end(c, EV_RANGES);
     }
@@ -609,6 +612,7 @@ static void dictionary_pipeline(pdl_ctx *c, bool only_complexity) {
         c->h_genome_cost.assign(pt + PDL_CTL_GCOST, pt + PDL_CTL_GCOST + c->G);
         memcpy(tail, pt, sizeof(tail));
     }
+    c->U = tail[0];
     c->Ushared = tail[2];
     // every record outside the shared groups is a group of its own: shared groups = all groups - singletons
     c->NG = c->dict_shard.empty() ? tail[1] - (c->U - c->Ushared) : 0;   // (not counted when only a shard's lists are built)

@@ -56,9 +56,22 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_u32(uint32_t v, uint32_
     return res;
 }
 
+// n = the element count; when d_n is set the count lives on the device (*d_n, at most n) and the grid was sized for the
+// bound n: the host does not have to read a count back before it can launch the kernels that depend on it.
+__device__ __forceinline__ uint64_t scan_count(uint64_t n, const uint64_t *d_n) {
+    if (!d_n) return n;
+    const uint64_t v = *d_n;
+    return v < n ? v : n;
+}
+
 template <class FlagF>
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_tile_sums(FlagF flag, uint64_t n, uint32_t *tile_sums) {
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_tile_sums(FlagF flag, uint64_t n_bound, const uint64_t *d_n, uint32_t *tile_sums) {
     __shared__ uint32_t s_wave[17];
+    const uint64_t n = scan_count(n_bound, d_n);
+    if ((uint64_t) blockIdx.x * SCAN_TILE >= n) {        // (uniform) tile past the end: contributes nothing
+        if (threadIdx.x == 0) tile_sums[blockIdx.x] = 0;
+        return;
+    }
     const uint64_t base = (uint64_t) blockIdx.x * SCAN_TILE;
     uint32_t sum = 0;
 #pragma unroll
@@ -99,11 +112,13 @@ static __global__ __launch_bounds__(1024) void k_scan_tile_scan(uint32_t *tile_s
 }
 
 template <class FlagF, class ApplyF>
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(FlagF flag, ApplyF apply, uint64_t n, const uint32_t *tile_sums) {
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(FlagF flag, ApplyF apply, uint64_t n_bound, const uint64_t *d_n, const uint32_t *tile_sums) {
     __shared__ uint32_t s_flags[SCAN_TILE];
     __shared__ uint32_t s_pref[SCAN_TILE];
     __shared__ uint32_t s_wave[17];
+    const uint64_t n = scan_count(n_bound, d_n);
     const uint64_t base = (uint64_t) blockIdx.x * SCAN_TILE;
+    if (base >= n) return;                               // (uniform)
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; j++) {           // coalesced flag evaluation
         const uint32_t li = j * SCAN_THREADS + threadIdx.x;
@@ -150,7 +165,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(FlagF flag, ApplyF 
 
 // Host wrapper.  d_total receives the grand total (u64).  scan_tmp is grown as needed.
 template <class FlagF, class ApplyF>
-inline void scan_and_apply(pdl_ctx *c, uint64_t n, FlagF flag, ApplyF apply, uint64_t *d_total, uint64_t *d_total2 = nullptr) {
+inline void scan_and_apply(pdl_ctx *c, uint64_t n, FlagF flag, ApplyF apply, uint64_t *d_total, uint64_t *d_total2 = nullptr,
+                           const uint64_t *d_n = nullptr /* count on the device, <= n */) {
     if (n == 0) {
         PDL_HIP(hipMemsetAsync(d_total, 0, sizeof(uint64_t), c->stream));
         if (d_total2) PDL_HIP(hipMemsetAsync(d_total2, 0, sizeof(uint64_t), c->stream));
@@ -161,8 +177,8 @@ inline void scan_and_apply(pdl_ctx *c, uint64_t n, FlagF flag, ApplyF apply, uin
     const uint32_t tiles = (uint32_t) tiles64;
     c->scan_tmp.alloc((size_t) tiles * sizeof(uint32_t));
     uint32_t *ts = c->scan_tmp.as<uint32_t>();
-    hipLaunchKernelGGL((k_scan_tile_sums<FlagF>), dim3(tiles), dim3(SCAN_THREADS), 0, c->stream, flag, n, ts);
+    hipLaunchKernelGGL((k_scan_tile_sums<FlagF>), dim3(tiles), dim3(SCAN_THREADS), 0, c->stream, flag, n, d_n, ts);
     hipLaunchKernelGGL(k_scan_tile_scan, dim3(1), dim3(1024), 0, c->stream, ts, tiles, d_total, d_total2);
-    hipLaunchKernelGGL((k_scan_apply<FlagF, ApplyF>), dim3(tiles), dim3(SCAN_THREADS), 0, c->stream, flag, apply, n, ts);
+    hipLaunchKernelGGL((k_scan_apply<FlagF, ApplyF>), dim3(tiles), dim3(SCAN_THREADS), 0, c->stream, flag, apply, n, d_n, ts);
     PDL_HIP(hipGetLastError());
 }

@@ -33,12 +33,17 @@ template <class KeyT>
 __device__ __forceinline__ uint32_t rs_digit(KeyT k, uint32_t shift) { return (uint32_t) (k >> shift) & 0xffu; }
 
 template <class KeyT>
-__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const KeyT *__restrict__ keys, uint64_t n, uint32_t shift, uint32_t n_tiles,
-                                                        uint32_t *__restrict__ counts) {
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const KeyT *__restrict__ keys, uint64_t n_bound, const uint64_t *d_n, uint32_t shift,
+                                                        uint32_t n_tiles, uint32_t *__restrict__ counts) {
     __shared__ uint32_t s_h[RS_BINS];
+    const uint64_t n = scan_count(n_bound, d_n);         // the count may live on the device (grid sized for the bound)
+    const uint64_t base = (uint64_t) blockIdx.x * RS_TILE;
+    if (base >= n) {                                     // (uniform) tile past the end
+        counts[(size_t) threadIdx.x * n_tiles + blockIdx.x] = 0;
+        return;
+    }
     s_h[threadIdx.x] = 0;
     __syncthreads();
-    const uint64_t base = (uint64_t) blockIdx.x * RS_TILE;
     KeyT key[RS_ROUNDS];
 #pragma unroll
     for (int j = 0; j < RS_ROUNDS; j++) {            // all sixteen loads in flight before the first LDS atomic
@@ -65,8 +70,10 @@ struct RsOffsApply {
 
 template <class KeyT>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const KeyT *__restrict__ keys_in, const uint32_t *vals_in,
-                                                           KeyT *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint64_t n,
-                                                           uint32_t shift, uint32_t n_tiles, const uint32_t *__restrict__ offs) {
+                                                           KeyT *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint64_t n_bound,
+                                                           const uint64_t *d_n, uint32_t shift, uint32_t n_tiles, const uint32_t *__restrict__ offs) {
+    const uint64_t n = scan_count(n_bound, d_n);
+    if ((uint64_t) blockIdx.x * (RS_THREADS * RS_ROUNDS) >= n) return;       // (uniform) tile past the end
     __shared__ KeyT s_key[RS_TILE];
     __shared__ uint32_t s_val[RS_TILE];
     __shared__ uint32_t s_cnt[RS_WAVES][RS_BINS];     // per wave: running count of each digit, then its base inside the tile
@@ -156,7 +163,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const KeyT *__restric
 
 template <class KeyT>
 void pdl_sort_pairs(pdl_ctx *c, KeyT *&keys_in, KeyT *&keys_out, uint32_t *&vals_in, uint32_t *&vals_out,
-                    uint64_t n, uint32_t end_bit, bool iota_values) {
+                    uint64_t n, uint32_t end_bit, bool iota_values, const uint64_t *d_n) {
     if (n == 0) return;
     if (end_bit == 0) end_bit = 1;
     if (end_bit > sizeof(KeyT) * 8) end_bit = sizeof(KeyT) * 8;
@@ -169,10 +176,10 @@ void pdl_sort_pairs(pdl_ctx *c, KeyT *&keys_in, KeyT *&keys_out, uint32_t *&vals
     const uint32_t passes = (end_bit + 7) / 8;
     for (uint32_t p = 0; p < passes; p++) {
         const uint32_t shift = p * 8;
-        hipLaunchKernelGGL((k_rs_hist<KeyT>), dim3(n_tiles), dim3(RS_THREADS), 0, c->stream, keys_in, n, shift, n_tiles, counts);
+        hipLaunchKernelGGL((k_rs_hist<KeyT>), dim3(n_tiles), dim3(RS_THREADS), 0, c->stream, keys_in, n, d_n, shift, n_tiles, counts);
         scan_and_apply(c, table, RsCountFlag{counts}, RsOffsApply{offs}, d_total);
         hipLaunchKernelGGL((k_rs_scatter<KeyT>), dim3(n_tiles), dim3(RS_THREADS), 0, c->stream, keys_in,
-                           (p == 0 && iota_values) ? (const uint32_t *) nullptr : vals_in, keys_out, vals_out, n, shift, n_tiles, offs);
+                           (p == 0 && iota_values) ? (const uint32_t *) nullptr : vals_in, keys_out, vals_out, n, d_n, shift, n_tiles, offs);
         PDL_HIP(hipGetLastError());
         std::swap(keys_in, keys_out);
         std::swap(vals_in, vals_out);
@@ -183,5 +190,5 @@ void pdl_sort_pairs(pdl_ctx *c, KeyT *&keys_in, KeyT *&keys_out, uint32_t *&vals
     std::swap(vals_in, vals_out);
 }
 
-template void pdl_sort_pairs<uint32_t>(pdl_ctx *, uint32_t *&, uint32_t *&, uint32_t *&, uint32_t *&, uint64_t, uint32_t, bool);
-template void pdl_sort_pairs<uint64_t>(pdl_ctx *, uint64_t *&, uint64_t *&, uint32_t *&, uint32_t *&, uint64_t, uint32_t, bool);
+template void pdl_sort_pairs<uint32_t>(pdl_ctx *, uint32_t *&, uint32_t *&, uint32_t *&, uint32_t *&, uint64_t, uint32_t, bool, const uint64_t *);
+template void pdl_sort_pairs<uint64_t>(pdl_ctx *, uint64_t *&, uint64_t *&, uint32_t *&, uint32_t *&, uint64_t, uint32_t, bool, const uint64_t *);

@@ -103,7 +103,6 @@ struct pdl_ctx {
     DevBuf kseq_len;      // u32 [N]
     DevBuf kmer_off;      // u64 [N+1]
     DevBuf cost;          // u64 [N]   total_visited
-    DevBuf genome_cost;   // u64 [G]
     std::vector<uint64_t> h_genome_cost;
 
     // sort buffers / dictionary
@@ -118,8 +117,7 @@ struct pdl_ctx {
     bool upper_only = false;  // ranges hold only the columns above the row: the join mirrors every cell
     DevBuf scan_tmp;      // block sums of the scans
     DevBuf scratch;       // transient buffers of the range build
-    DevBuf scalars;       // u64 [16] device-side totals
-    DevBuf hist;          // u64 [256]
+    DevBuf scalars;       // control block, u64: totals [16] | residue histogram [256] | per-genome cost [G] (PDL_CTL_*)
 
     // genome / task layout (host and device)
     std::vector<uint32_t> h_genome_of;

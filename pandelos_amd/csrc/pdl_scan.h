@@ -111,13 +111,36 @@ static __global__ __launch_bounds__(1024) void k_scan_tile_scan(uint32_t *tile_s
     }
 }
 
-template <class FlagF, class ApplyF>
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(FlagF flag, ApplyF apply, uint64_t n_bound, const uint64_t *d_n, const uint32_t *tile_sums) {
+// INLINE_PREFIX (short scans, <= SCAN_INLINE_TILES tiles): tile_sums holds the raw sums and every workgroup adds up the
+// ones before its own tile itself (a few hundred L2-resident words) — the one-workgroup launch between the two passes,
+// which is mostly launch latency, is gone; workgroup 0 writes the grand total.
+constexpr uint32_t SCAN_INLINE_TILES = 1024;
+template <class FlagF, class ApplyF, bool INLINE_PREFIX>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(FlagF flag, ApplyF apply, uint64_t n_bound, const uint64_t *d_n, const uint32_t *tile_sums,
+                                                            uint64_t *d_total, uint64_t *d_total2) {
     __shared__ uint32_t s_flags[SCAN_TILE];
     __shared__ uint32_t s_pref[SCAN_TILE];
     __shared__ uint32_t s_wave[17];
     const uint64_t n = scan_count(n_bound, d_n);
     const uint64_t base = (uint64_t) blockIdx.x * SCAN_TILE;
+    uint32_t tile_prefix = 0;
+    if constexpr (INLINE_PREFIX) {
+        const uint32_t upto = blockIdx.x == 0 ? gridDim.x : blockIdx.x;      // workgroup 0 adds up everything: the total
+        uint32_t part = 0;
+        for (uint32_t i = threadIdx.x; i < upto; i += SCAN_THREADS) part += tile_sums[i];
+        uint32_t all;
+        (void) block_exclusive_scan_u32(part, s_wave, all);
+        if (blockIdx.x == 0) {
+            if (threadIdx.x == 0) {
+                *d_total = all;
+                if (d_total2) { reinterpret_cast<uint32_t *>(d_total2)[0] = all; reinterpret_cast<uint32_t *>(d_total2)[1] = 0u; }
+            }
+        } else {
+            tile_prefix = all;
+        }
+    } else {
+        tile_prefix = tile_sums[blockIdx.x];
+    }
     if (base >= n) return;                               // (uniform)
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; j++) {           // coalesced flag evaluation
@@ -132,7 +155,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(FlagF flag, ApplyF 
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; j++) { f[j] = s_flags[threadIdx.x * SCAN_ITEMS + j]; sum += f[j]; }
     uint32_t total;
-    uint32_t prefix = block_exclusive_scan_u32(sum, s_wave, total) + tile_sums[blockIdx.x];
+    uint32_t prefix = block_exclusive_scan_u32(sum, s_wave, total) + tile_prefix;
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; j++) { s_pref[threadIdx.x * SCAN_ITEMS + j] = prefix; prefix += f[j]; }
     __syncthreads();
@@ -178,7 +201,11 @@ inline void scan_and_apply(pdl_ctx *c, uint64_t n, FlagF flag, ApplyF apply, uin
     c->scan_tmp.alloc((size_t) tiles * sizeof(uint32_t));
     uint32_t *ts = c->scan_tmp.as<uint32_t>();
     hipLaunchKernelGGL((k_scan_tile_sums<FlagF>), dim3(tiles), dim3(SCAN_THREADS), 0, c->stream, flag, n, d_n, ts);
-    hipLaunchKernelGGL(k_scan_tile_scan, dim3(1), dim3(1024), 0, c->stream, ts, tiles, d_total, d_total2);
-    hipLaunchKernelGGL((k_scan_apply<FlagF, ApplyF>), dim3(tiles), dim3(SCAN_THREADS), 0, c->stream, flag, apply, n, d_n, ts);
+    if (tiles <= SCAN_INLINE_TILES) {
+        hipLaunchKernelGGL((k_scan_apply<FlagF, ApplyF, true>), dim3(tiles), dim3(SCAN_THREADS), 0, c->stream, flag, apply, n, d_n, ts, d_total, d_total2);
+    } else {
+        hipLaunchKernelGGL(k_scan_tile_scan, dim3(1), dim3(1024), 0, c->stream, ts, tiles, d_total, d_total2);
+        hipLaunchKernelGGL((k_scan_apply<FlagF, ApplyF, false>), dim3(tiles), dim3(SCAN_THREADS), 0, c->stream, flag, apply, n, d_n, ts, d_total, d_total2);
+    }
     PDL_HIP(hipGetLastError());
 }

@@ -224,25 +224,30 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ == 10) ? 5 : 1) void k_join
             }
             sum += len[j];
         }
-        uint32_t total;
-        uint32_t ex = block_exclusive_scan_u32(sum, s_wave, total);
-        // every wave walks a contiguous segment of the flat lookup space: segment w starts at lookup w * seg
+        // exclusive prefix over the workgroup with ONE barrier: wave scans, wave totals through LDS, and every thread adds
+        // up the (at most 16) totals of the waves before its own — the staging costs two barriers per batch, not five
         constexpr uint32_t NW = T / PDL_WAVE;
+        const uint32_t inc = wave_inclusive_scan_u32(sum);
+        if ((tid & (PDL_WAVE - 1)) == PDL_WAVE - 1) s_wave[tid / PDL_WAVE] = inc;
+        __syncthreads();
+        uint32_t total = 0, wave_off = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < NW; w++) { const uint32_t t = s_wave[w]; wave_off += w < tid / PDL_WAVE ? t : 0u; total += t; }
+        uint32_t ex = inc - sum + wave_off;
+        // every wave walks a contiguous segment of the flat lookup space: segment w starts at lookup w * seg
         const uint32_t chunks = (total + PDL_WAVE - 1) / PDL_WAVE;
         const uint32_t seg = ((chunks + NW - 1) / NW) * PDL_WAVE;
 #pragma unroll
         for (uint32_t j = 0; j < RPT; j++) {
             const uint32_t i = tid * RPT + j;
-            s_cum[i] = i < nb ? ex : 0xffffffffu;
+            s_cum[i] = i < nb ? ex : (i == nb ? total : 0xffffffffu);     // s_cum[nb] = total: > every flat index
             if (len[j]) {                                    // the range that holds a segment's first lookup registers itself
                 const uint32_t w_lo = seg ? (ex + seg - 1) / seg : 0;        // first w with w * seg >= ex
                 for (uint32_t w = w_lo; w < NW && w * seg < ex + len[j]; w++) s_wstart[w] = make_uint2(i, ex);
             }
             ex += len[j];
         }
-        if (tid == 0) s_cum[RB] = 0xffffffffu;
-        __syncthreads();
-        if (tid == 0) s_cum[nb] = total;                     // > every flat index
+        if (tid == 0) s_cum[RB] = nb == RB ? total : 0xffffffffu;
         __syncthreads();
         return total;
     };

@@ -656,6 +656,7 @@ struct OrderArgs {
     int32_t *c_row, *c_col;
     uint32_t n_rows;
     uint32_t canonical;
+    uint32_t *wide_rows;                // set by k_order_rows_wave when it leaves a row to k_order_rows
 };
 
 __device__ __forceinline__ unsigned long long order_key_hi(uint32_t col, uint32_t first, uint32_t canonical) {
@@ -675,10 +676,12 @@ __device__ __forceinline__ OrderCell order_cell(const OrderArgs &a, uint32_t p, 
 __global__ __launch_bounds__(ORDER_THREADS) void k_order_rows(OrderArgs a) {
     __shared__ unsigned long long s_hi[ORDER_TILE];
     __shared__ uint32_t s_col[ORDER_TILE];
-    const uint32_t p = blockIdx.x;
+    if (*a.wide_rows == 0) return;               // no row is wider than the wave kernel's limit (the usual case)
+  for (uint32_t p = blockIdx.x; p < a.n_rows; p += gridDim.x) {       // persistent workgroups: rows dealt round-robin
     const uint32_t own = a.row_cnt[p];
     const uint32_t cnt = own + (a.mirror_cnt ? a.mirror_cnt[p] : 0u);
-    if (cnt <= ORDER_WAVE_CELLS) return;         // k_order_rows_wave's rows
+    if (cnt <= ORDER_WAVE_CELLS) continue;       // k_order_rows_wave's rows (uniform)
+    __syncthreads();                             // the LDS tiles of the previous row are done with
     const uint32_t out0 = a.fin_off[p];
     const uint32_t row = a.task_rows[p];
     if (cnt <= ORDER_TILE) {
@@ -724,7 +727,7 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_order_rows(OrderArgs a) {
             a.c_row[o] = (int32_t) row;
             a.c_col[o] = (int32_t) s_col[q];
         }
-        return;
+        continue;
     }
     for (uint32_t i0 = 0; i0 < cnt; i0 += ORDER_THREADS) {
         const uint32_t i = i0 + threadIdx.x;
@@ -765,6 +768,7 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_order_rows(OrderArgs a) {
             a.c_col[o] = (int32_t) col;
         }
     }
+  }
 }
 
 // Rows of at most 256 cells (nearly all rows of most datasets): one wave per row, up to four cells per lane, the keys
@@ -775,6 +779,7 @@ __global__ __launch_bounds__(256) void k_order_rows_wave(OrderArgs a) {
     const uint32_t lane = threadIdx.x & (PDL_WAVE - 1);
     const uint32_t own = a.row_cnt[p];
     const uint32_t cnt = own + (a.mirror_cnt ? a.mirror_cnt[p] : 0u);
+    if (cnt > ORDER_WAVE_CELLS && lane == 0) *a.wide_rows = 1;       // (plain store of the same value from whoever sees one)
     if (cnt == 0 || cnt > ORDER_WAVE_CELLS) return;      // (wave-uniform)
     const uint32_t nslots = (cnt + PDL_WAVE - 1) / PDL_WAVE;
     uint32_t col[ORDER_CPL], hi_lo[ORDER_CPL], hi_hi[ORDER_CPL], rank[ORDER_CPL];
@@ -1114,8 +1119,9 @@ void pdl_run_score_all(pdl_ctx *c) {
         o.c_score = c->c_score.as<float>(); o.c_perc = c->c_perc.as<float>(); o.c_tr = c->c_tr.as<float>();
         o.c_row = c->c_row.as<int32_t>(); o.c_col = c->c_col.as<int32_t>();
         o.n_rows = n_rows; o.canonical = (c->flags & PDL_FLAG_CANONICAL_ORDER) ? 1u : 0u;
+        o.wide_rows = ctr32 + 9;                 // (counter block, zero since the clearing launch)
         hipLaunchKernelGGL(k_order_rows_wave, dim3((n_rows + 3) / 4), dim3(256), 0, st, o);
-        hipLaunchKernelGGL(k_order_rows, dim3(n_rows), dim3(ORDER_THREADS), 0, st, o);     // rows of more than 256 cells; the others leave at once
+        hipLaunchKernelGGL(k_order_rows, dim3(std::min<uint32_t>(n_rows, (uint32_t) cus * 8)), dim3(ORDER_THREADS), 0, st, o);   // rows of more than 256 cells, if any
         PDL_HIP(hipGetLastError());
         ev_end(c, EV_ORDER);
 

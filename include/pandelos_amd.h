@@ -55,7 +55,7 @@ typedef struct {
     uint64_t kmer_occurrences;  /* M  = sum over genes of max(len-k+1, 0) */
     uint64_t dictionary_records;/* U  = unique (rank, gene) records (library.cpp:280-287) */
     uint64_t shared_records;    /* U' = records in rank-groups with >= 2 records (= posting ranges, library.cpp:318-326) */
-    uint64_t groups;            /* rank-groups with >= 2 records */
+    uint64_t groups;            /* rank-groups with >= 2 records (multi-GPU: counted over the whole dictionary as well) */
     uint64_t total_cost;        /* P  = "Total cost: P lookups" (library.cpp:327,349) */
     float linear_ratio;         /* P / sum kseq_lengths (library.cpp:350) */
     uint32_t sequences;         /* N */
@@ -97,6 +97,11 @@ typedef struct {
     uint64_t overflow_rows;        /* rows that left the LDS tables for the HBM table (tier 3) */
     uint32_t join_launches;
     uint32_t tier2_rows;           /* rows the filtered small-table tier handed to the big LDS table */
+    /* multi-GPU passes (zero otherwise) */
+    float dist_begin_ms, dist_finish_ms;   /* pdl_dist_preprocess_begin / _finish, device time */
+    float dist_score_begin_ms, dist_score_finish_ms;
+    uint64_t walked_lookups;       /* postings the join actually read: each unordered pair of a group once when rows only meet the genes above them */
+    uint64_t outbox_cells, inbox_cells;
 } pdl_timings;
 
 PDL_API pdl_ctx *pdl_create(const pdl_config *cfg /* may be NULL */);
@@ -152,6 +157,62 @@ PDL_API int pdl_get_dictionary(pdl_ctx *, uint64_t *ranks, uint32_t *seqs, uint3
 PDL_API int pdl_get_rank_table(const pdl_ctx *, uint8_t out_rank_values[256], uint64_t *out_last_multiplier);
 
 PDL_API int pdl_get_timings(pdl_ctx *, pdl_timings *out);
+
+/* Tuning / test switches of one context (no environment variable is read by the library).  Unknown names fail with
+ * PDL_ERR_ARGUMENT.  Options: "join_tier1" 0|9|10|11|20|21 (table of the join's first tier; -1 = default: by genome count),
+ * "join_tiny_tier2" 0|1 (512-slot second tier, so that small test sets reach the HBM-table kernel), "host_mirror" 0|1
+ * (pdl_compute_scores slices ONE pinned copy of the whole result (1, default) or copies each genome's block from the
+ * device (0); results above 1 GiB always take the second way), "staging_cap" n (cells of staging the first scoring
+ * attempt may use, 0 = estimate; a pass that overflows it is repeated once with the exact size). */
+PDL_API int pdl_set_option(pdl_ctx *, const char *name, int64_t value);
+
+/* ---- multi-GPU: one context per GPU, the caller moves bytes between them (RCCL over xGMI) -----------------------
+ * Counterpart of the reference's per-genome tasks on a thread pool over ONE shared dictionary (Pangenes.java:54-66,
+ * library.cpp:73): here every GPU holds the whole dictionary, built co-operatively, and scores a disjoint set of genomes.
+ * All ranks call the same sequence with the SAME input (every host reads the .faa); nothing below communicates by
+ * itself — the caller owns the collectives (pandelos_amd/distributed.py: torch.distributed):
+ *
+ *   pdl_dist_preprocess_begin   histogram, rank table, k-mer ranks (every rank, from the shared input); the rank space is
+ *                               cut into `world` intervals of ~equal k-mer counts (same cuts on every rank: they depend on
+ *                               the input only) and this rank sorts + dedups ITS interval (library.cpp:270-287 on 1/world
+ *                               of the records).  Result: its run of the dictionary, pdl_dist_slice.
+ *   -- caller: all-gather the record counts, then the runs themselves into ONE device array in rank order
+ *      (the concatenation IS the dictionary in (rank, gene) order: no merge) --
+ *   pdl_dist_preprocess_finish  adopts that array (must stay valid until the next preprocess), builds the rank-groups
+ *                               (library.cpp:289-335), deals the genomes to ranks (longest-processing-time on each
+ *                               genome's lookups above the diagonal, computed identically everywhere) and builds the
+ *                               posting-range lists of this rank's genes.
+ *   pdl_dist_score_begin        scores this rank's rows against the genes ABOVE them only; a cell whose column belongs to
+ *                               another rank's genome is also that rank's cell (c, r) (same sums, perc/tr_perc swapped):
+ *                               such cells are listed per destination rank, pdl_dist_outbox.
+ *   -- caller: all-to-all the per-destination counts, then the 24-byte cells --
+ *   pdl_dist_score_finish       files the received cells with the local ones, folds them into the per-(row, genome) and
+ *                               per-column maxima and puts every row in the reference's emission order.
+ * Afterwards pdl_compute_scores / pdl_scores_counts work for the genomes of this rank (pdl_dist_genome_owner). */
+typedef struct {
+    const void *d_postings;   /* device, records x 8 bytes {gene u32, count u32 | group-head flag in bit 31} */
+    uint64_t records;         /* unique (rank, gene) records of this rank's interval */
+    uint64_t kmers;           /* k-mer occurrences of this rank's interval */
+} pdl_dist_slice;
+
+typedef struct { float score, perc, tr_perc; uint32_t row, column, first_group; } pdl_dist_cell;   /* cell (row, column) as its row's rank computed it */
+
+typedef struct {
+    const pdl_dist_cell *d_cells;  /* device, grouped by destination rank in rank order */
+    const uint64_t *counts;        /* host, [world]: cells for each rank (0 for this rank itself); valid until the next call on this context */
+    uint64_t total;
+} pdl_dist_outbox;
+
+PDL_API int pdl_dist_preprocess_begin(pdl_ctx *, const uint8_t *d_residues, const uint64_t *d_offsets, const uint32_t *d_genome_of,
+                                      uint32_t n_sequences, uint64_t n_residues, int kvalue, uint32_t world, uint32_t rank,
+                                      pdl_dist_slice *out);
+PDL_API int pdl_dist_preprocess_finish(pdl_ctx *, void *d_postings_all, uint64_t total_records, pdl_cost *out_cost /* may be NULL */);
+PDL_API int pdl_dist_genome_owner(const pdl_ctx *, uint32_t *out_owner /* [G] */);
+PDL_API int pdl_dist_score_begin(pdl_ctx *, pdl_dist_outbox *out);
+PDL_API int pdl_dist_score_finish(pdl_ctx *, const pdl_dist_cell *d_inbox, uint64_t n_inbox);
+/* dst[0..bytes) = src[0..bytes), both on this context's device, queued on its stream and waited for (the runs and
+ * outboxes above live in library-owned memory, the exchange buffers in the caller's). */
+PDL_API int pdl_copy_device(pdl_ctx *, void *d_dst, const void *d_src, uint64_t bytes);
 
 /* Library/build identification, e.g. "pandelos_amd 0.1 gfx950" */
 PDL_API const char *pdl_version(void);

@@ -52,17 +52,32 @@ class PdlTimings(C.Structure):
                 ("join_overflow_ms", C.c_float), ("order_ms", C.c_float), ("preprocess_total_ms", C.c_float),
                 ("score_total_ms", C.c_float), ("emitted_cells", C.c_uint64), ("scored_rows", C.c_uint64),
                 ("scored_lookups", C.c_uint64), ("overflow_rows", C.c_uint64), ("join_launches", C.c_uint32),
-                ("tier2_rows", C.c_uint32)]
+                ("tier2_rows", C.c_uint32),
+                ("dist_begin_ms", C.c_float), ("dist_finish_ms", C.c_float), ("dist_score_begin_ms", C.c_float),
+                ("dist_score_finish_ms", C.c_float), ("walked_lookups", C.c_uint64), ("outbox_cells", C.c_uint64),
+                ("inbox_cells", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+
+
+class PdlDistSlice(C.Structure):
+    _fields_ = [("d_postings", C.c_void_p), ("records", C.c_uint64), ("kmers", C.c_uint64)]
+
+
+class PdlDistOutbox(C.Structure):
+    _fields_ = [("d_cells", C.c_void_p), ("counts", C.POINTER(C.c_uint64)), ("total", C.c_uint64)]
+
+
+DIST_CELL_BYTES = 24      # pdl_dist_cell: 3 x f32 + 3 x u32
 
 
 # every symbol include/pandelos_amd.h declares (tests/test_boundary.py checks the export table against this)
 EXPORTS = ("pdl_create", "pdl_destroy", "pdl_last_error", "pdl_preprocess", "pdl_preprocess_device",
            "pdl_genome_cost", "pdl_sequence_costs", "pdl_set_genome_shard", "pdl_score_all", "pdl_compute_scores",
            "pdl_free_scores", "pdl_scores_counts", "pdl_get_dictionary", "pdl_get_rank_table", "pdl_get_timings",
-           "pdl_version")
+           "pdl_version", "pdl_set_option", "pdl_dist_preprocess_begin", "pdl_dist_preprocess_finish",
+           "pdl_dist_genome_owner", "pdl_dist_score_begin", "pdl_dist_score_finish", "pdl_copy_device")
 
 _lib = None
 
@@ -101,5 +116,13 @@ def load():
     lib.pdl_get_rank_table.argtypes = [vp, vp, C.POINTER(u64)]; lib.pdl_get_rank_table.restype = i32
     lib.pdl_get_timings.argtypes = [vp, C.POINTER(PdlTimings)]; lib.pdl_get_timings.restype = i32
     lib.pdl_version.argtypes = []; lib.pdl_version.restype = C.c_char_p
+    lib.pdl_set_option.argtypes = [vp, C.c_char_p, C.c_int64]; lib.pdl_set_option.restype = i32
+    lib.pdl_dist_preprocess_begin.argtypes = [vp, vp, vp, vp, u32, u64, i32, u32, u32, C.POINTER(PdlDistSlice)]
+    lib.pdl_dist_preprocess_begin.restype = i32
+    lib.pdl_dist_preprocess_finish.argtypes = [vp, vp, u64, C.POINTER(PdlCost)]; lib.pdl_dist_preprocess_finish.restype = i32
+    lib.pdl_dist_genome_owner.argtypes = [vp, vp]; lib.pdl_dist_genome_owner.restype = i32
+    lib.pdl_dist_score_begin.argtypes = [vp, C.POINTER(PdlDistOutbox)]; lib.pdl_dist_score_begin.restype = i32
+    lib.pdl_dist_score_finish.argtypes = [vp, vp, u64]; lib.pdl_dist_score_finish.restype = i32
+    lib.pdl_copy_device.argtypes = [vp, vp, vp, u64]; lib.pdl_copy_device.restype = i32
     _lib = lib
     return lib

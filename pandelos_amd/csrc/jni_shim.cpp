@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
+#include <string>
 #include <vector>
 
 namespace {
@@ -89,6 +90,23 @@ void Java_infoasys_cli_pangenes_PangeneNative_preprocessSequences(pj_env env, pj
     if (!g_ctx) {
         g_ctx = pdl_create(nullptr);
         if (!g_ctx) die("no usable HIP device", nullptr);
+        // The Java signatures leave no room for settings, so the drop-in takes them from the environment, once:
+        // PANDELOS_AMD_OPTIONS="name=value,name=value" -> pdl_set_option (the library itself reads no environment).
+        if (const char *opts = getenv("PANDELOS_AMD_OPTIONS")) {
+            std::string all(opts);
+            size_t at = 0;
+            while (at < all.size()) {
+                size_t end = all.find(',', at);
+                if (end == std::string::npos) end = all.size();
+                const std::string item = all.substr(at, end - at);
+                const size_t eq = item.find('=');
+                if (eq == std::string::npos || pdl_set_option(g_ctx, item.substr(0, eq).c_str(), atoll(item.c_str() + eq + 1)) != PDL_OK) {
+                    fprintf(stderr, "pandelos_amd (libnative.so): bad PANDELOS_AMD_OPTIONS item '%s'\n", item.c_str());
+                    exit(1);
+                }
+                at = end + 1;
+            }
+        }
     }
     pdl_cost cost;
     const int rc = pdl_preprocess(g_ctx, residues.data(), offsets.data(), genome_of.data(), (uint32_t) n, kvalue,

@@ -103,6 +103,7 @@ static int preprocess_common(pdl_ctx *c, uint32_t n, uint64_t n_res, int k, int 
     if (n == 0) PDL_FAIL(PDL_ERR_EMPTY, "empty dataset");
     build_genome_layout(c);
     c->dict_shard.clear();
+    if (c->dist) { c->shard.clear(); c->shard_set = false; c->dist = false; c->dist_stage = 0; }    // (a multi-GPU build's own deal does not carry over)
     if (c->shard_set) {
         for (uint32_t g : c->shard)
             if (g >= c->G) PDL_FAIL(PDL_ERR_ARGUMENT, "genome shard: id %u out of range (%u genomes)", g, c->G);
@@ -113,6 +114,24 @@ static int preprocess_common(pdl_ctx *c, uint32_t n, uint64_t n_res, int k, int 
     fill_cost(c, out_cost);
     return PDL_OK;
     PDL_GUARD_END(c)
+}
+
+// device-resident input: genome ids come to the host (task layout), and the two ends of the offsets are checked against
+// n_res (a wrong n_res would make the ranking kernels read past the residues; ascending order is checked by K-len)
+static void adopt_device_input(pdl_ctx *c, const uint8_t *d_residues, const uint64_t *d_offsets, const uint32_t *d_genome_of,
+                               uint32_t n, uint64_t n_res) {
+    c->d_res = d_residues; c->d_off = d_offsets; c->d_gen = d_genome_of;
+    c->h_genome_of.resize(n);
+    uint64_t ends[2] = {0, n_res};
+    if (n) {
+        PDL_HIP(hipMemcpyAsync(c->h_genome_of.data(), d_genome_of, (size_t) n * 4, hipMemcpyDeviceToHost, c->stream));
+        PDL_HIP(hipMemcpyAsync(&ends[0], d_offsets, 8, hipMemcpyDeviceToHost, c->stream));
+        PDL_HIP(hipMemcpyAsync(&ends[1], d_offsets + n, 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    PDL_HIP(hipStreamSynchronize(c->stream));
+    if (ends[0] != 0 || ends[1] != n_res)
+        PDL_FAIL(PDL_ERR_ARGUMENT, "offsets[0] = %llu, offsets[n] = %llu do not span the %llu residues", (unsigned long long) ends[0],
+                 (unsigned long long) ends[1], (unsigned long long) n_res);
 }
 
 int pdl_preprocess(pdl_ctx *c, const uint8_t *residues, const uint64_t *offsets, const uint32_t *genome_of,
@@ -143,10 +162,7 @@ int pdl_preprocess_device(pdl_ctx *c, const uint8_t *d_residues, const uint64_t 
     if (!d_offsets || !d_genome_of || (!d_residues && n_res)) PDL_FAIL(PDL_ERR_ARGUMENT, "null input pointer");
     if (((uintptr_t) d_residues & 15) != 0) PDL_FAIL(PDL_ERR_ARGUMENT, "d_residues must be 16-byte aligned");
     PDL_HIP(hipSetDevice(c->device));
-    c->d_res = d_residues; c->d_off = d_offsets; c->d_gen = d_genome_of;
-    c->h_genome_of.resize(n);
-    if (n) PDL_HIP(hipMemcpyAsync(c->h_genome_of.data(), d_genome_of, (size_t) n * 4, hipMemcpyDeviceToHost, c->stream));
-    PDL_HIP(hipStreamSynchronize(c->stream));
+    adopt_device_input(c, d_residues, d_offsets, d_genome_of, n, n_res);
     PDL_GUARD_END(c)
     return preprocess_common(c, n, n_res, k, only_complexity, out_cost);
 }
@@ -162,8 +178,8 @@ int pdl_genome_cost(const pdl_ctx *c, uint32_t genome, uint64_t *out) {
 int pdl_sequence_costs(const pdl_ctx *cc, uint64_t *out_cost, uint32_t *out_kseq) {
     pdl_ctx *c = const_cast<pdl_ctx *>(cc);
     if (!c || !out_cost) return PDL_ERR_ARGUMENT;
-    if (!c->preprocessed) return PDL_ERR_STATE;
     std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->preprocessed) return PDL_ERR_STATE;
     PDL_GUARD_BEGIN
     PDL_HIP(hipSetDevice(c->device));
     PDL_HIP(hipMemcpyAsync(out_cost, c->cost.p, (size_t) c->N * 8, hipMemcpyDeviceToHost, c->stream));
@@ -176,6 +192,7 @@ int pdl_sequence_costs(const pdl_ctx *cc, uint64_t *out_cost, uint32_t *out_kseq
 int pdl_set_genome_shard(pdl_ctx *c, const uint32_t *genomes, uint32_t count) {
     if (!c || (!genomes && count)) return PDL_ERR_ARGUMENT;
     std::lock_guard<std::mutex> lk(c->mu);
+    if (c->dist && c->dist_stage) { c->err = "genome shard: a multi-GPU build deals the genomes itself (pdl_dist_genome_owner)"; return PDL_ERR_STATE; }
     std::vector<uint32_t> s(genomes, genomes + count);
     std::sort(s.begin(), s.end());
     for (size_t i = 0; i < s.size(); i++) {
@@ -208,6 +225,7 @@ static int score_all_locked(pdl_ctx *c) {
     if (!c->preprocessed) PDL_FAIL(PDL_ERR_STATE, "pdl_score_all before pdl_preprocess");
     if (c->only_complexity) PDL_FAIL(PDL_ERR_STATE, "the dictionary was built in complexity-only mode (no posting ranges)");
     if (c->scored) return PDL_OK;
+    if (c->dist) PDL_FAIL(PDL_ERR_STATE, "multi-GPU context: score with pdl_dist_score_begin / pdl_dist_score_finish");
     PDL_HIP(hipSetDevice(c->device));
     c->mirror_valid = false;
     pdl_run_score_all(c);
@@ -241,39 +259,84 @@ void pdl_free_scores(pdl_scores *s) {
     memset(s, 0, sizeof(*s));
 }
 
+// Device -> host copy for one calling thread, without the context lock: a stream and two pinned bounce buffers per
+// thread (results beyond the host mirror's limit: the Java pool calls computeScores from ThreadsNum threads at once,
+// Pangenes.java:54-66; the device arrays are immutable between scoring and the next preprocess).
+namespace {
+struct ThreadCopier {
+    static constexpr size_t CHUNK = (size_t) 4 << 20;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    uint8_t *buf[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    void open(int dev) {
+        if (device == dev && stream) return;
+        close();
+        PDL_HIP(hipSetDevice(dev));
+        PDL_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) {
+            PDL_HIP(hipHostMalloc((void **) &buf[i], CHUNK, hipHostMallocDefault));
+            PDL_HIP(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+        }
+        device = dev;
+    }
+    void close() {
+        for (int i = 0; i < 2; i++) { if (buf[i]) (void) hipHostFree(buf[i]); if (ev[i]) (void) hipEventDestroy(ev[i]); buf[i] = nullptr; ev[i] = nullptr; }
+        if (stream) (void) hipStreamDestroy(stream);
+        stream = nullptr; device = -1;
+    }
+    // dst (pageable) = src (device): chunk i+1 is in flight while chunk i is copied out of its bounce buffer
+    void fetch(void *dst, const void *src, size_t bytes) {
+        uint8_t *d = static_cast<uint8_t *>(dst);
+        const uint8_t *sp = static_cast<const uint8_t *>(src);
+        size_t issued = 0, drained = 0;
+        int slot = 0;
+        size_t len[2] = {0, 0};
+        while (drained < bytes) {
+            if (issued < bytes && (issued - drained) < 2 * CHUNK) {
+                const size_t n = std::min(CHUNK, bytes - issued);
+                PDL_HIP(hipMemcpyAsync(buf[slot], sp + issued, n, hipMemcpyDeviceToHost, stream));
+                PDL_HIP(hipEventRecord(ev[slot], stream));
+                len[slot] = n; issued += n; slot ^= 1;
+                if (issued < bytes && issued - drained < 2 * CHUNK) continue;
+            }
+            const int dslot = (int) ((drained / CHUNK) & 1);
+            PDL_HIP(hipEventSynchronize(ev[dslot]));
+            memcpy(d + drained, buf[dslot], len[dslot]);
+            drained += len[dslot];
+        }
+    }
+    ~ThreadCopier() { close(); }
+};
+thread_local ThreadCopier t_copier;
+}  // namespace
+
 int pdl_compute_scores(pdl_ctx *c, uint32_t genome, pdl_scores *out) {
     if (!c || !out) return PDL_ERR_ARGUMENT;
     memset(out, 0, sizeof(*out));
-    std::lock_guard<std::mutex> lk(c->mu);     // device copies are serialised; host threads may call concurrently
-    int rc = score_all_locked(c);
-    if (rc != PDL_OK) return rc;
-    PDL_GUARD_BEGIN
-    if (genome >= c->G) PDL_FAIL(PDL_ERR_ARGUMENT, "genome %u out of range (%u genomes)", genome, c->G);
-    const int32_t lg = c->h_local_genome[genome];
-    if (lg < 0) PDL_FAIL(PDL_ERR_ARGUMENT, "genome %u is not in this context's shard", genome);
-    PDL_HIP(hipSetDevice(c->device));
-    hipStream_t st = c->stream;
-    const uint32_t N = c->N, G = c->G;
-    const uint64_t z0 = c->h_cell_off[lg], z1 = c->h_cell_off[lg + 1];
-    const uint32_t z = (uint32_t) (z1 - z0);
-    const uint32_t p0 = c->h_task_row_off[lg], rows = c->h_task_row_off[lg + 1] - p0;
-    out->scoresCount = z; out->rows = rows; out->genomes = G; out->sequences = N;
-    out->scores = xalloc<float>(z); out->percs = xalloc<float>(z); out->tr_percs = xalloc<float>(z);
-    out->row = xalloc<int32_t>(z); out->column = xalloc<int32_t>(z);
-    out->first_seq_genome = xalloc<int32_t>(z); out->second_seq_genome = xalloc<int32_t>(z);
-    out->max_genome_score = xalloc<float>((size_t) rows * G);
-    out->max_genome_score_col = xalloc<float>(N);
-    out->scoresMaxMappings = xalloc<int32_t>(N);
-    // Results up to PDL_MIRROR_LIMIT come to the host once, into pinned memory, with one copy per array; the per-genome
-    // calls (the reference's thread pool makes G of them, Pangenes.java:54-66) then only slice that mirror.
-    const uint64_t Zall = c->h_cell_off.back();
-    const size_t S = c->shard.size();
-    const size_t b_cells = (size_t) Zall * 4, b_ms = (size_t) c->n_task_rows * G * 4, b_cm = S * (size_t) N * 4;
-    const size_t need = 5 * b_cells + b_ms + b_cm;
-    constexpr size_t PDL_MIRROR_LIMIT = (size_t) 1 << 30;
-    const char *mirror_env = getenv("PDL_HOST_MIRROR");          // "0": per-genome device copies (the path of larger results), for tests
-    if (need <= PDL_MIRROR_LIMIT && !(mirror_env && mirror_env[0] == '0')) {
-        if (!c->mirror_valid) {
+    try {
+    bool use_mirror = false;
+    size_t b_cells = 0, b_ms = 0;
+    {
+        // The lock covers the scoring pass (first call) and the one-time fill of the host mirror; slicing a genome's block
+        // out of either the mirror or the device arrays runs without it, so the pool's threads do not serialise.
+        std::lock_guard<std::mutex> lk(c->mu);
+        int rc = c->scored ? PDL_OK : score_all_locked(c);
+        if (rc != PDL_OK) return rc;
+        if (genome >= c->G) PDL_FAIL(PDL_ERR_ARGUMENT, "genome %u out of range (%u genomes)", genome, c->G);
+        if (c->h_local_genome[genome] < 0) PDL_FAIL(PDL_ERR_ARGUMENT, "genome %u is not in this context's shard", genome);
+        // Results up to PDL_MIRROR_LIMIT come to the host once, into pinned memory, with one copy per array; the per-genome
+        // calls (the reference's thread pool makes G of them, Pangenes.java:54-66) then only slice that mirror.
+        const uint64_t Zall = c->h_cell_off.back();
+        const size_t S = c->shard.size();
+        b_cells = (size_t) Zall * 4; b_ms = (size_t) c->n_task_rows * c->G * 4;
+        const size_t b_cm = S * (size_t) c->N * 4;
+        const size_t need = 5 * b_cells + b_ms + b_cm;
+        constexpr size_t PDL_MIRROR_LIMIT = (size_t) 1 << 30;
+        use_mirror = need <= PDL_MIRROR_LIMIT && c->opt_host_mirror;
+        if (use_mirror && !c->mirror_valid) {
+            PDL_HIP(hipSetDevice(c->device));
+            hipStream_t st = c->stream;
             if (c->mirror_bytes < need) {
                 if (c->mirror) { (void) hipHostFree(c->mirror); c->mirror = nullptr; c->mirror_bytes = 0; }
                 PDL_HIP(hipHostMalloc((void **) &c->mirror, need + need / 4 + 64, hipHostMallocDefault));
@@ -288,22 +351,37 @@ int pdl_compute_scores(pdl_ctx *c, uint32_t genome, pdl_scores *out) {
             PDL_HIP(hipStreamSynchronize(st));
             c->mirror_valid = true;
         }
+    }
+    const int32_t lg = c->h_local_genome[genome];
+    const uint32_t N = c->N, G = c->G;
+    const uint64_t z0 = c->h_cell_off[lg], z1 = c->h_cell_off[lg + 1];
+    const uint32_t z = (uint32_t) (z1 - z0);
+    const uint32_t p0 = c->h_task_row_off[lg], rows = c->h_task_row_off[lg + 1] - p0;
+    out->scoresCount = z; out->rows = rows; out->genomes = G; out->sequences = N;
+    out->scores = xalloc<float>(z); out->percs = xalloc<float>(z); out->tr_percs = xalloc<float>(z);
+    out->row = xalloc<int32_t>(z); out->column = xalloc<int32_t>(z);
+    out->first_seq_genome = xalloc<int32_t>(z); out->second_seq_genome = xalloc<int32_t>(z);
+    out->max_genome_score = xalloc<float>((size_t) rows * G);
+    out->max_genome_score_col = xalloc<float>(N);
+    out->scoresMaxMappings = xalloc<int32_t>(N);
+    if (use_mirror) {
         const uint8_t *m = c->mirror;
         void *dst[5] = {out->scores, out->percs, out->tr_percs, out->row, out->column};
         for (int i = 0; i < 5; i++) if (z) memcpy(dst[i], m + (size_t) i * b_cells + (size_t) z0 * 4, (size_t) z * 4);
         if (rows) memcpy(out->max_genome_score, m + 5 * b_cells + (size_t) p0 * G * 4, (size_t) rows * G * 4);
         memcpy(out->max_genome_score_col, m + 5 * b_cells + b_ms + (size_t) lg * N * 4, (size_t) N * 4);
     } else {
+        ThreadCopier &tc = t_copier;
+        tc.open(c->device);
         if (z) {
-            PDL_HIP(hipMemcpyAsync(out->scores, c->c_score.as<float>() + z0, (size_t) z * 4, hipMemcpyDeviceToHost, st));
-            PDL_HIP(hipMemcpyAsync(out->percs, c->c_perc.as<float>() + z0, (size_t) z * 4, hipMemcpyDeviceToHost, st));
-            PDL_HIP(hipMemcpyAsync(out->tr_percs, c->c_tr.as<float>() + z0, (size_t) z * 4, hipMemcpyDeviceToHost, st));
-            PDL_HIP(hipMemcpyAsync(out->row, c->c_row.as<int32_t>() + z0, (size_t) z * 4, hipMemcpyDeviceToHost, st));
-            PDL_HIP(hipMemcpyAsync(out->column, c->c_col.as<int32_t>() + z0, (size_t) z * 4, hipMemcpyDeviceToHost, st));
+            tc.fetch(out->scores, c->c_score.as<float>() + z0, (size_t) z * 4);
+            tc.fetch(out->percs, c->c_perc.as<float>() + z0, (size_t) z * 4);
+            tc.fetch(out->tr_percs, c->c_tr.as<float>() + z0, (size_t) z * 4);
+            tc.fetch(out->row, c->c_row.as<int32_t>() + z0, (size_t) z * 4);
+            tc.fetch(out->column, c->c_col.as<int32_t>() + z0, (size_t) z * 4);
         }
-        if (rows) PDL_HIP(hipMemcpyAsync(out->max_genome_score, c->MS.as<float>() + (size_t) p0 * G, (size_t) rows * G * 4, hipMemcpyDeviceToHost, st));
-        PDL_HIP(hipMemcpyAsync(out->max_genome_score_col, c->CM.as<float>() + (size_t) lg * N, (size_t) N * 4, hipMemcpyDeviceToHost, st));
-        PDL_HIP(hipStreamSynchronize(st));
+        if (rows) tc.fetch(out->max_genome_score, c->MS.as<float>() + (size_t) p0 * G, (size_t) rows * G * 4);
+        tc.fetch(out->max_genome_score_col, c->CM.as<float>() + (size_t) lg * N, (size_t) N * 4);
     }
     // library.cpp:571-575: genome of row / column per cell;  :428-432: flat map
     for (uint32_t i = 0; i < z; i++) {
@@ -313,8 +391,112 @@ int pdl_compute_scores(pdl_ctx *c, uint32_t genome, pdl_scores *out) {
     for (uint32_t i = 0; i < N; i++) out->scoresMaxMappings[i] = std::numeric_limits<int32_t>::max();
     for (uint32_t j = 0; j < rows; j++) out->scoresMaxMappings[c->h_genome_rows[c->h_genome_row_off[genome] + j]] = (int32_t) j;
     return PDL_OK;
-    } catch (const pdl_error &e) { c->err = e.msg; pdl_free_scores(out); return e.code;
-    } catch (const std::bad_alloc &) { c->err = "host allocation failed"; pdl_free_scores(out); return PDL_ERR_DEVICE; }
+    } catch (const pdl_error &e) { { std::lock_guard<std::mutex> lk(c->mu); c->err = e.msg; } pdl_free_scores(out); return e.code;
+    } catch (const std::bad_alloc &) { { std::lock_guard<std::mutex> lk(c->mu); c->err = "host allocation failed"; } pdl_free_scores(out); return PDL_ERR_DEVICE; }
+}
+
+int pdl_set_option(pdl_ctx *c, const char *name, int64_t value) {
+    if (!c || !name) return PDL_ERR_ARGUMENT;
+    std::lock_guard<std::mutex> lk(c->mu);
+    const std::string n(name);
+    if (n == "join_tier1") {
+        if (!(value == -1 || value == 0 || (value >= 9 && value <= 11) || value == 20 || value == 21)) { c->err = "join_tier1: -1, 0, 9, 10, 11, 20 or 21"; return PDL_ERR_ARGUMENT; }
+        c->opt_tier1 = (int) value;
+    } else if (n == "join_tiny_tier2") c->opt_tiny_tier2 = value != 0;
+    else if (n == "host_mirror") c->opt_host_mirror = value != 0;
+    else if (n == "staging_cap") c->opt_staging_cap = value > 0 ? (uint64_t) value : 0;
+    else { c->err = "unknown option " + n; return PDL_ERR_ARGUMENT; }
+    c->scored = false;        // the next scoring call runs with the new setting
+    return PDL_OK;
+}
+
+// ---- multi-GPU (see include/pandelos_amd.h) -------------------------------------------------------------------------
+int pdl_dist_preprocess_begin(pdl_ctx *c, const uint8_t *d_residues, const uint64_t *d_offsets, const uint32_t *d_genome_of,
+                              uint32_t n, uint64_t n_res, int k, uint32_t world, uint32_t rank, pdl_dist_slice *out) {
+    if (!c || !out) return PDL_ERR_ARGUMENT;
+    std::lock_guard<std::mutex> lk(c->mu);
+    PDL_GUARD_BEGIN
+    if (!d_offsets || !d_genome_of || (!d_residues && n_res)) PDL_FAIL(PDL_ERR_ARGUMENT, "null input pointer");
+    if (((uintptr_t) d_residues & 15) != 0) PDL_FAIL(PDL_ERR_ARGUMENT, "d_residues must be 16-byte aligned");
+    if (world == 0 || rank >= world || world > 64) PDL_FAIL(PDL_ERR_ARGUMENT, "rank %u of %u (at most 64 ranks)", rank, world);
+    PDL_HIP(hipSetDevice(c->device));
+    c->preprocessed = false; c->scored = false; c->tasks_ready = false; c->mirror_valid = false;
+    c->dist = false; c->dist_stage = 0;
+    adopt_device_input(c, d_residues, d_offsets, d_genome_of, n, n_res);
+    c->N = n; c->R = n_res;
+    c->U = c->Ushared = c->NG = c->P = c->M = 0;
+    if (k <= 0) PDL_FAIL(PDL_ERR_KVALUE, "K value must be greater than 0.");
+    if (n == 0) PDL_FAIL(PDL_ERR_EMPTY, "empty dataset");
+    build_genome_layout(c);
+    c->world = world; c->rank = rank;
+    c->shard.clear(); c->shard_set = false; c->dict_shard.clear();
+    pdl_run_dist_begin(c, k);
+    out->d_postings = c->post.p; out->records = c->U_slice; out->kmers = c->M_slice;
+    return PDL_OK;
+    PDL_GUARD_END(c)
+}
+
+int pdl_dist_preprocess_finish(pdl_ctx *c, void *d_postings_all, uint64_t total_records, pdl_cost *out_cost) {
+    if (!c) return PDL_ERR_ARGUMENT;
+    std::lock_guard<std::mutex> lk(c->mu);
+    PDL_GUARD_BEGIN
+    if (!c->dist || c->dist_stage != 1) PDL_FAIL(PDL_ERR_STATE, "pdl_dist_preprocess_finish without pdl_dist_preprocess_begin");
+    if (!d_postings_all || ((uintptr_t) d_postings_all & 7) != 0) PDL_FAIL(PDL_ERR_ARGUMENT, "the gathered dictionary must be an 8-byte aligned device array");
+    if (total_records < c->U_slice) PDL_FAIL(PDL_ERR_ARGUMENT, "the gathered dictionary (%llu records) is smaller than this rank's run (%llu)",
+                                             (unsigned long long) total_records, (unsigned long long) c->U_slice);
+    PDL_HIP(hipSetDevice(c->device));
+    c->post_ext = static_cast<uint2 *>(d_postings_all);
+    pdl_run_dist_finish(c, total_records);
+    c->preprocessed = true;
+    fill_cost(c, out_cost);
+    return PDL_OK;
+    PDL_GUARD_END(c)
+}
+
+int pdl_dist_genome_owner(const pdl_ctx *c, uint32_t *out) {
+    if (!c || !out) return PDL_ERR_ARGUMENT;
+    if (!c->dist || c->dist_stage < 2) return PDL_ERR_STATE;
+    memcpy(out, c->h_owner.data(), (size_t) c->G * 4);
+    return PDL_OK;
+}
+
+int pdl_dist_score_begin(pdl_ctx *c, pdl_dist_outbox *out) {
+    if (!c || !out) return PDL_ERR_ARGUMENT;
+    std::lock_guard<std::mutex> lk(c->mu);
+    PDL_GUARD_BEGIN
+    if (!c->dist || c->dist_stage < 2) PDL_FAIL(PDL_ERR_STATE, "pdl_dist_score_begin before pdl_dist_preprocess_finish");
+    PDL_HIP(hipSetDevice(c->device));
+    c->scored = false; c->mirror_valid = false; c->dist_stage = 2;
+    pdl_run_dist_score_begin(c);
+    out->d_cells = c->outbox.as<pdl_dist_cell>();
+    out->counts = c->h_outbox_counts.data();
+    out->total = 0;
+    for (uint64_t v : c->h_outbox_counts) out->total += v;
+    return PDL_OK;
+    PDL_GUARD_END(c)
+}
+
+int pdl_dist_score_finish(pdl_ctx *c, const pdl_dist_cell *d_inbox, uint64_t n_inbox) {
+    if (!c || (!d_inbox && n_inbox)) return PDL_ERR_ARGUMENT;
+    std::lock_guard<std::mutex> lk(c->mu);
+    PDL_GUARD_BEGIN
+    if (!c->dist || c->dist_stage != 3) PDL_FAIL(PDL_ERR_STATE, "pdl_dist_score_finish without pdl_dist_score_begin");
+    if (n_inbox >= 0xffffffffull) PDL_FAIL(PDL_ERR_UNSUPPORTED, "more than 2^32 received cells");
+    PDL_HIP(hipSetDevice(c->device));
+    pdl_run_dist_score_finish(c, d_inbox, n_inbox);
+    return PDL_OK;
+    PDL_GUARD_END(c)
+}
+
+int pdl_copy_device(pdl_ctx *c, void *d_dst, const void *d_src, uint64_t bytes) {
+    if (!c || ((!d_dst || !d_src) && bytes)) return PDL_ERR_ARGUMENT;
+    std::lock_guard<std::mutex> lk(c->mu);
+    PDL_GUARD_BEGIN
+    PDL_HIP(hipSetDevice(c->device));
+    if (bytes) PDL_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    PDL_HIP(hipStreamSynchronize(c->stream));
+    return PDL_OK;
+    PDL_GUARD_END(c)
 }
 
 int pdl_get_dictionary(pdl_ctx *c, uint64_t *ranks, uint32_t *seqs, uint32_t *counts) {
@@ -322,6 +504,7 @@ int pdl_get_dictionary(pdl_ctx *c, uint64_t *ranks, uint32_t *seqs, uint32_t *co
     std::lock_guard<std::mutex> lk(c->mu);
     PDL_GUARD_BEGIN
     if (!c->preprocessed) PDL_FAIL(PDL_ERR_STATE, "pdl_get_dictionary before pdl_preprocess");
+    if (c->dist) PDL_FAIL(PDL_ERR_STATE, "pdl_get_dictionary: a multi-GPU context keeps ranks only for its own interval");
     PDL_HIP(hipSetDevice(c->device));
     const uint64_t U = c->U, M = c->M;
     std::vector<uint32_t> recpos(U);

@@ -58,6 +58,18 @@ struct DevBuf {
     }
     template <class T> T *as() const { return static_cast<T *>(p); }
     ~DevBuf() { release(); }
+    void grow_keep(size_t n, hipStream_t st) {   // grows and keeps the contents (a device copy on `st`, waited for)
+        if (n <= bytes && p) return;
+        void *q = nullptr;
+        PDL_HIP(hipMalloc(&q, n));
+        if (p && bytes) {
+            PDL_HIP(hipMemcpyAsync(q, p, bytes, hipMemcpyDeviceToDevice, st));
+            PDL_HIP(hipStreamSynchronize(st));
+            (void) hipFree(p);
+        }
+        p = q;
+        bytes = n;
+    }
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
@@ -153,12 +165,36 @@ struct pdl_ctx {
     DevBuf st_src, taskpos_of, mirror_cnt, mirror_ref;   // mirror mode (see pdl_join.hip)
     std::vector<uint32_t> h_task_rows_host, h_task_lg_host, h_taskpos_host, h_fin;
     bool tasks_ready = false;  // task layout uploaded for the current shard
-    DevBuf scratch2;
+    DevBuf scratch2;      // small transient device scratch (interval histogram, per-genome lookups)
+    DevBuf task_off;      // u32 [shard+1] task offsets | gathered cell offsets + 8 counters + cell total
     int cus = 0;
     uint32_t occ_tier1[5] = {0, 0, 0, 0, 0};
 
+    // tuning / test switches (pdl_set_option)
+    int opt_tier1 = -1;           // -1: by genome count
+    bool opt_tiny_tier2 = false;
+    bool opt_host_mirror = true;
+    uint64_t opt_staging_cap = 0; // 0: estimate
+
+    // multi-GPU (pdl_dist_*): this context is rank `rank` of `world`; the postings live in caller-owned memory
+    bool dist = false;
+    uint32_t world = 1, rank = 0;
+    int dist_stage = 0;           // 0 none | 1 slice built | 2 dictionary adopted | 3 join done, outbox listed | 4 scored
+    uint2 *post_ext = nullptr;    // the all-gathered dictionary (caller's buffer), used instead of `post`
+    uint64_t U_slice = 0, M_slice = 0;
+    std::vector<uint32_t> h_owner;            // [G] rank of every genome
+    std::vector<uint64_t> h_upper_cost;       // [G] lookups above the diagonal per genome (what a rank's join walks)
+    DevBuf owner_of_genome;                   // u32 [G]
+    DevBuf local_genome;                      // u32 [G] index in the shard, 0xffffffff for other ranks' genomes
+    DevBuf outbox;                            // pdl_dist_cell [remote mirrored cells], grouped by destination rank
+    DevBuf outbox_tab;                        // u32 [workgroups][world] counts, then offsets
+    std::vector<uint64_t> h_outbox_counts;    // [world]
+    uint64_t st_local = 0;                    // staging slots below this hold the cells of this rank's own rows
+    uint64_t n_inbox = 0;
+    uint32_t order_grid1 = 0;
+
     pdl_timings tm{};
-    EventPair ev[12];
+    EventPair ev[16];
     uint8_t *pin = nullptr;       // pinned host scratch for the small device->host reads (true async DMA, no staging copy)
     size_t pin_bytes = 0;
     // host mirror of the whole scoring result (pinned): filled by ONE set of device->host copies at the first
@@ -193,11 +229,17 @@ struct PinRead {
 
 // stage entry points (pdl_dict.hip / pdl_join.hip)
 void pdl_run_preprocess(pdl_ctx *c, int kvalue, bool only_complexity);
+void pdl_run_dist_begin(pdl_ctx *c, int kvalue);
+void pdl_run_dist_finish(pdl_ctx *c, uint64_t total_records);
 void pdl_run_score_all(pdl_ctx *c);
+void pdl_run_dist_score_begin(pdl_ctx *c);
+void pdl_run_dist_score_finish(pdl_ctx *c, const pdl_dist_cell *d_inbox, uint64_t n_inbox);
 void pdl_prepare_tasks(pdl_ctx *c);
+inline uint2 *pdl_postings(const pdl_ctx *c) { return c->post_ext ? c->post_ext : c->post.as<uint2>(); }
 
 // event helpers
-enum { EV_HIST, EV_RANK, EV_SORT1, EV_DICT, EV_SORT2, EV_RANGES, EV_JOIN, EV_JOIN_OVF, EV_ORDER, EV_PRE_TOTAL, EV_SCORE_TOTAL, EV_COUNT };
+enum { EV_HIST, EV_RANK, EV_SORT1, EV_DICT, EV_SORT2, EV_RANGES, EV_JOIN, EV_JOIN_OVF, EV_ORDER, EV_PRE_TOTAL, EV_SCORE_TOTAL,
+       EV_DIST_BEGIN, EV_DIST_FINISH, EV_DIST_SCORE_FINISH, EV_COUNT };
 
 inline void ev_begin(pdl_ctx *c, int i) {
     if (!c->ev[i].a) { PDL_HIP(hipEventCreate(&c->ev[i].a)); PDL_HIP(hipEventCreate(&c->ev[i].b)); }

@@ -103,17 +103,20 @@ static void rank_init_host(RankParams &rp, const uint64_t counters[256], int kva
 struct KseqFlag {
     const uint64_t *off; uint32_t k;
     __device__ uint32_t operator()(uint64_t i) const {
-        uint64_t len = off[i + 1] - off[i];
+        const uint64_t b = off[i], e = off[i + 1];
+        const uint64_t len = e >= b ? e - b : 0;        // (descending offsets are reported by KseqApply)
         return len >= k ? (uint32_t) (len - k + 1) : 0u;
     }
 };
 struct KseqApply {
     uint32_t *kseq_len; uint64_t *kmer_off;   // kmer_off as u64 for the API; values < 2^32 (checked on the host)
     unsigned long long *cost;                 // total_visited starts at zero (spares a fill)
+    const uint64_t *off; uint64_t n_res; unsigned long long *bad;    // *bad |= 1 when the offsets are not an ascending cover of [0, n_res]
     __device__ void operator()(uint64_t i, uint32_t f, uint32_t prefix) const {
         kseq_len[i] = f;
         kmer_off[i] = prefix;
         cost[i] = 0;
+        if (off[i + 1] < off[i] || off[i + 1] > n_res) atomicOr(bad, 1ull);     // (never taken on valid input)
     }
 };
 
@@ -146,15 +149,28 @@ __device__ __forceinline__ uint64_t load_residues8(const uint8_t *__restrict__ r
     return w;
 }
 
-template <class KeyT>
+// Interval histogram of the multi-GPU build: the rank space is cut where the top DIST_BIN_BITS bits of a rank change.
+constexpr uint32_t DIST_BIN_BITS = 12, DIST_BINS = 1u << DIST_BIN_BITS;
+
+// MODE 0: keys[q] = rank, vals[q] = gene for every slot q of the k-mer stream (one workgroup per tile).
+// MODE 1: only counts the ranks by their top bits into bins[DIST_BINS] (persistent workgroups over the tiles, LDS
+//         histogram, one global atomic per non-empty bin and workgroup): the k-mer count of every rank interval, from
+//         which pdl_dist_preprocess_begin derives the same cuts on every GPU.
+template <class KeyT, int MODE>
 __global__ __launch_bounds__(RANK_THREADS) void k_rank(const uint8_t *__restrict__ res, const uint64_t *__restrict__ off,
                                                        const uint64_t *__restrict__ kmer_off, uint32_t n_seq, uint64_t m, uint64_t n_res,
-                                                       RankParams rp, KeyT *__restrict__ keys, uint32_t *__restrict__ vals) {
+                                                       RankParams rp, KeyT *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                       uint32_t bin_shift, uint32_t *__restrict__ bins) {
     __shared__ uint8_t s_rv[256];
     __shared__ uint32_t s_lo, s_hi;
     __shared__ uint64_t s_koff[RANK_SPAN + 1], s_off[RANK_SPAN];    // k-mer and residue offsets of the genes this tile touches
+    __shared__ uint32_t s_bins[MODE == 1 ? DIST_BINS : 1];
     for (int i = threadIdx.x; i < 256; i += RANK_THREADS) s_rv[i] = rp.rank_values[i];
-    const uint64_t q0 = (uint64_t) blockIdx.x * RANK_TILE;
+    if constexpr (MODE == 1) for (uint32_t i = threadIdx.x; i < DIST_BINS; i += RANK_THREADS) s_bins[i] = 0;
+    const uint64_t tiles = (m + RANK_TILE - 1) / RANK_TILE;
+  for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {      // MODE 0: grid = tiles, one trip
+    __syncthreads();                                            // (the staged boundaries of the previous tile are done with)
+    const uint64_t q0 = tile * RANK_TILE;
     const uint64_t q_last = min(q0 + RANK_TILE, m) - 1;
     if (threadIdx.x == 0) s_lo = upper_bound_u64(kmer_off, 0, n_seq + 1, q0) - 1;
     if (threadIdx.x == 64) s_hi = upper_bound_u64(kmer_off, 0, n_seq + 1, q_last) - 1;
@@ -211,7 +227,15 @@ __global__ __launch_bounds__(RANK_THREADS) void k_rank(const uint8_t *__restrict
 #pragma unroll
     for (int j = 0; j < RANK_ITEMS; j++) {
         const uint64_t q = q0 + (uint64_t) j * RANK_THREADS + threadIdx.x;
-        if (q < m) { keys[q] = r[j]; vals[q] = sq[j]; }
+        if (q < m) {
+            if constexpr (MODE == 1) atomicAdd(&s_bins[(uint32_t) (r[j] >> bin_shift)], 1u);
+            else { keys[q] = r[j]; vals[q] = sq[j]; }
+        }
+    }
+  }
+    if constexpr (MODE == 1) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < DIST_BINS; i += RANK_THREADS) { const uint32_t v = s_bins[i]; if (v) atomicAdd(&bins[i], v); }
     }
 }
 
@@ -232,9 +256,11 @@ __device__ __forceinline__ uint64_t update_rank_hash_dev(uint64_t current, uint6
     return r;
 }
 
+// MODE 1 counts the ranks by their top DIST_BIN_BITS bits instead of writing them (see k_rank).
+template <int MODE>
 __global__ __launch_bounds__(256) void k_rank_hash(const uint8_t *__restrict__ res, const uint64_t *__restrict__ off,
                                                    const uint64_t *__restrict__ kmer_off, uint32_t n_seq, RankParams rp,
-                                                   uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+                                                   uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t *__restrict__ bins) {
     __shared__ uint8_t s_rv[256];
     for (int i = threadIdx.x; i < 256; i += 256) s_rv[i] = rp.rank_values[i];
     __syncthreads();
@@ -249,10 +275,10 @@ __global__ __launch_bounds__(256) void k_rank_hash(const uint8_t *__restrict__ r
     uint64_t rank = 0;
     const uint64_t v0 = s_rv[0];
     for (uint32_t i = 0; i < k; i++) rank = update_rank_hash_dev(rank, s_rv[p[i]], v0, rp.last_multiplier, rp.base);
-    keys[q] = rank; vals[q] = s; q++;
+    if constexpr (MODE == 1) atomicAdd(&bins[rank >> (64 - DIST_BIN_BITS)], 1u); else { keys[q] = rank; vals[q] = s; q++; }
     for (uint64_t i = k; i < len; i++) {
         rank = update_rank_hash_dev(rank, s_rv[p[i]], s_rv[p[i - k]], rp.last_multiplier, rp.base);
-        keys[q] = rank; vals[q] = s; q++;
+        if constexpr (MODE == 1) atomicAdd(&bins[rank >> (64 - DIST_BIN_BITS)], 1u); else { keys[q] = rank; vals[q] = s; q++; }
     }
 }
 
@@ -276,6 +302,7 @@ template <class KeyT> struct RecHead {
 template <class KeyT> struct RecScatter {
     const KeyT *keys; const uint32_t *vals; uint64_t m;
     uint32_t *recpos; uint2 *post; uint8_t *ghead;
+    uint32_t pack_head;     // 1: the head flag also rides in bit 31 of the count (the form a rank's run travels in, pdl_dist_slice)
     struct Loaded { uint32_t val, run; uint8_t head; };
     __device__ Loaded load(uint64_t q, uint32_t) const {    // straight-line for the common run of one; the rare longer run loops
         const uint64_t qp = q ? q - 1 : 0, qn = q + 1 < m ? q + 1 : q;
@@ -292,7 +319,7 @@ template <class KeyT> struct RecScatter {
     __device__ void store(uint64_t q, uint32_t f, uint32_t prefix, const Loaded &v) const {
         if (!f) return;
         recpos[prefix] = (uint32_t) q;
-        post[prefix] = make_uint2(v.val, v.run);
+        post[prefix] = make_uint2(v.val, v.run | (((uint32_t) v.head & pack_head) << 31));
         ghead[prefix] = v.head;
     }
 };
@@ -313,6 +340,35 @@ struct GroupScatter {
         if (u == u_count - 1) goff[prefix + f] = (uint32_t) u_count;      // closes the offsets: goff[number of groups] = U
     }
 };
+// The same scan over an all-gathered dictionary (multi-GPU): the head flags arrive in bit 31 of the counts and are
+// taken out again by the apply step (every workgroup has evaluated its tile's flags before its first store).
+struct GroupHeadFlagPacked {
+    const uint2 *post; const uint64_t *d_u;
+    __device__ uint32_t operator()(uint64_t u) const { const uint64_t u_count = *d_u; return (u_count >= 2 && u == u_count - 1) ? 0u : post[u].y >> 31; }
+};
+struct GroupScatterStrip {
+    uint32_t *gid; uint32_t *goff; const uint64_t *d_u; uint2 *post;
+    struct Loaded { uint32_t cnt; };
+    __device__ Loaded load(uint64_t u, uint32_t) const { return Loaded{post[u].y}; }
+    __device__ void store(uint64_t u, uint32_t f, uint32_t prefix, const Loaded &v) const {
+        gid[u] = prefix + f - 1;
+        if (f) goff[prefix] = (uint32_t) u;
+        const uint64_t u_count = *d_u;
+        if (u == u_count - 1) goff[prefix + f] = (uint32_t) u_count;
+        if (v.cnt >> 31) post[u].y = v.cnt & 0x7fffffffu;
+    }
+};
+// Interval selection of the multi-GPU build: the k-mers whose rank falls into this GPU's bins, in stream order.
+template <class KeyT> struct SelFlag {
+    const KeyT *keys; uint32_t shift, b_lo, b_hi;
+    __device__ uint32_t operator()(uint64_t q) const { const uint32_t b = (uint32_t) (keys[q] >> shift); return (uint32_t) (b >= b_lo) & (uint32_t) (b < b_hi); }
+};
+template <class KeyT> struct SelApply {
+    const KeyT *keys; const uint32_t *vals; KeyT *keys_out; uint32_t *vals_out;
+    struct Loaded { KeyT key; uint32_t val; };
+    __device__ Loaded load(uint64_t q, uint32_t) const { return Loaded{keys[q], vals[q]}; }
+    __device__ void store(uint64_t, uint32_t f, uint32_t prefix, const Loaded &v) const { if (f) { keys_out[prefix] = v.key; vals_out[prefix] = v.val; } }
+};
 
 // The reference re-sorts every shared group by gene (library.cpp:312-315).  After the stable sort all groups
 // already are in gene order except the last one when the globally last record was folded into it (:300-306):
@@ -326,7 +382,7 @@ __global__ __launch_bounds__(1024) void k_fold_last_record(uint2 *__restrict__ p
     const uint32_t gs = goff[*d_ng - 1];
     const uint32_t lastp = u_count - 1;
     const uint2 last = post[lastp];
-    const uint32_t last_rp = recpos[lastp];
+    const uint32_t last_rp = recpos ? recpos[lastp] : 0u;      // (no recpos over an all-gathered dictionary)
     if (threadIdx.x == 0) {
         uint32_t lo = gs, hi = lastp;                    // first index in [gs, lastp) whose gene is above the last record's
         while (lo < hi) {
@@ -343,13 +399,61 @@ __global__ __launch_bounds__(1024) void k_fold_last_record(uint2 *__restrict__ p
         const uint32_t i = hi - 1 - threadIdx.x;
         uint2 v = make_uint2(0, 0);
         uint32_t rp = 0;
-        if (live) { v = post[i]; rp = recpos[i]; }
+        if (live) { v = post[i]; if (recpos) rp = recpos[i]; }
         __syncthreads();
-        if (live) { post[i + 1] = v; recpos[i + 1] = rp; }
+        if (live) { post[i + 1] = v; if (recpos) recpos[i + 1] = rp; }
         __syncthreads();
         if (hi <= 1024) break;
     }
-    if (threadIdx.x == 0) { post[p] = last; recpos[p] = last_rp; }
+    if (threadIdx.x == 0) { post[p] = last; if (recpos) recpos[p] = last_rp; }
+}
+
+// Counters over the whole dictionary, one grid-stride pass: records in shared groups (U'), shared groups, and — multi-GPU —
+// every genome's lookups as the reference counts them ("Genome g cost", library.cpp:327,535-538: each record of a shared
+// group adds the group size) and above the diagonal (the postings after the record: what the symmetric join walks).
+// Sums are kept per lane, reduced per wave and workgroup; genome sums go through an LDS table (G <= COST_LDS_GENOMES,
+// global atomics beyond that).  out[0] += U', out[1] += groups.
+constexpr uint32_t COST_LDS_GENOMES = 4096;
+template <bool GENOMES>
+__global__ __launch_bounds__(256) void k_dictionary_counters(const uint2 *__restrict__ post, const uint32_t *__restrict__ gid,
+                                                             const uint32_t *__restrict__ goff, const uint64_t *d_u,
+                                                             const uint32_t *__restrict__ genome_of, uint32_t n_genomes,
+                                                             unsigned long long *__restrict__ out,
+                                                             unsigned long long *__restrict__ g_full, unsigned long long *__restrict__ g_upper) {
+    __shared__ unsigned long long s_full[GENOMES ? COST_LDS_GENOMES : 1], s_upper[GENOMES ? COST_LDS_GENOMES : 1];
+    __shared__ uint32_t s_cnt[2];
+    const bool lds_table = GENOMES && n_genomes <= COST_LDS_GENOMES;
+    if constexpr (GENOMES) { if (lds_table) for (uint32_t i = threadIdx.x; i < n_genomes; i += 256) { s_full[i] = 0; s_upper[i] = 0; } }
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t u_count = (uint32_t) *d_u;
+    uint32_t n_rec = 0, n_grp = 0;
+    for (uint64_t u0 = (uint64_t) blockIdx.x * 256; u0 < u_count; u0 += (uint64_t) gridDim.x * 256) {
+        const uint32_t u = (uint32_t) u0 + threadIdx.x;
+        if (u >= u_count) continue;
+        const uint32_t g = gid[u];
+        const uint32_t gs = goff[g], ge = goff[g + 1];
+        if (ge - gs < 2) continue;
+        n_rec++;
+        n_grp += u == gs;
+        if constexpr (GENOMES) {
+            const uint32_t gen = genome_of[post[u].x];
+            const unsigned long long full = ge - gs, upper = ge - u - 1;
+            if (lds_table) { atomicAdd(&s_full[gen], full); if (upper) atomicAdd(&s_upper[gen], upper); }
+            else { atomicAdd(&g_full[gen], full); if (upper) atomicAdd(&g_upper[gen], upper); }
+        }
+    }
+#pragma unroll
+    for (int d = PDL_WAVE / 2; d > 0; d >>= 1) { n_rec += __shfl_xor(n_rec, d, PDL_WAVE); n_grp += __shfl_xor(n_grp, d, PDL_WAVE); }
+    if ((threadIdx.x & (PDL_WAVE - 1)) == 0) { atomicAdd(&s_cnt[0], n_rec); atomicAdd(&s_cnt[1], n_grp); }
+    __syncthreads();
+    if (threadIdx.x < 2 && s_cnt[threadIdx.x]) atomicAdd(&out[threadIdx.x], (unsigned long long) s_cnt[threadIdx.x]);
+    if constexpr (GENOMES) {
+        if (lds_table) for (uint32_t i = threadIdx.x; i < n_genomes; i += 256) {
+            if (s_full[i]) atomicAdd(&g_full[i], s_full[i]);
+            if (s_upper[i]) atomicAdd(&g_upper[i], s_upper[i]);
+        }
+    }
 }
 
 // total_visited (library.cpp:327) straight from the records: every record of a group with >= 2 records
@@ -385,14 +489,16 @@ __global__ __launch_bounds__(256) void k_record_costs(const uint2 *__restrict__ 
 //   3. one gather of the 16-byte tuples through the sorted indices          [one random 16 B read each]
 // (Slot allocation with global atomics was measured 4x slower than the sort: device-scope atomics on
 // scattered counters run at the memory side on this chip.)
-template <bool UPPER_ONLY> struct SharedFlag {         // the mode is a template parameter: the per-item code stays straight-line
+// MODE 0: whole groups for the genes of a shard | 1: upper ranges for every gene | 2: upper ranges for the genes of a shard
+template <int MODE> struct SharedFlag {              // the mode is a template parameter: the per-item code stays straight-line
     const uint32_t *gid; const uint32_t *goff;
-    const uint2 *post; const uint8_t *in_shard;      // !UPPER_ONLY: only the genes of the shard get range lists
+    const uint2 *post; const uint8_t *in_shard;      // MODE 0, 2: only the genes of the shard get range lists
     __device__ uint32_t operator()(uint64_t u) const {
         const uint32_t g = gid[u];
         const uint32_t gs = goff[g], ge = goff[g + 1];
         const uint32_t shared = (uint32_t) (ge - gs >= 2);
-        if constexpr (UPPER_ONLY) return shared & (uint32_t) ((uint32_t) u + 1 < ge);   // the last member of a group has nothing above it
+        if constexpr (MODE == 1) return shared & (uint32_t) ((uint32_t) u + 1 < ge);   // the last member of a group has nothing above it
+        else if constexpr (MODE == 2) return shared & (uint32_t) ((uint32_t) u + 1 < ge) & (uint32_t) in_shard[post[u].x];
         else return shared & (uint32_t) in_shard[post[u].x];
     }
 };
@@ -401,6 +507,7 @@ struct SharedScatter {
     uint32_t *key2; uint4 *tuples;
     uint32_t upper_only;       // 1: a gene's range covers only the postings AFTER its own record (genes above it)
     unsigned long long *cost;  // upper_only: the group size of a group's last member is added here (it has no range)
+    const uint8_t *in_shard;   // upper_only with a shard: only its genes keep costs
     struct Loaded { uint32_t gs, ge; uint2 po; };
     __device__ Loaded load(uint64_t u, uint32_t) const {
         const uint32_t g = gid[u];
@@ -408,7 +515,8 @@ struct SharedScatter {
     }
     __device__ void store(uint64_t u, uint32_t f, uint32_t prefix, const Loaded &v) const {
         if (!f) {
-            if (upper_only && v.ge - v.gs >= 2 && (uint32_t) u + 1 == v.ge) atomicAdd(&cost[v.po.x], (unsigned long long) (v.ge - v.gs));
+            if (upper_only && v.ge - v.gs >= 2 && (uint32_t) u + 1 == v.ge && (!in_shard || in_shard[v.po.x]))
+                atomicAdd(&cost[v.po.x], (unsigned long long) (v.ge - v.gs));
             return;
         }
         const uint32_t start = upper_only ? (uint32_t) u + 1 : v.gs;
@@ -493,147 +601,22 @@ __global__ __launch_bounds__(256) void k_genome_cost(const unsigned long long *_
 }
 
 // ------------------------------------------------------------------------------------------------
-template <class KeyT>
-static void dictionary_pipeline(pdl_ctx *c, bool only_complexity) {
-    hipStream_t st = c->stream;
-    const uint64_t M = c->M;
-    uint64_t *d_scal = c->scalars.as<uint64_t>();
+// Host side of the stages.  Control block words (c->scalars, u64): 0 U | 1 groups of any size | 2 ranges built |
+// 3 bad-offsets flag | 4 sum kseq | 5 M | 6 emitted cells | 7 max kseq | 8 ~min kseq | 9 mirrored cells |
+// 10 U' | 11 shared groups | 15 sort scratch | PDL_CTL_HIST.. histogram | PDL_CTL_GCOST.. per-genome cost
+// ------------------------------------------------------------------------------------------------
 
-    // (the control block — scalars, histogram, per-genome costs — was zeroed in one go by pdl_run_preprocess:
-    //  3-4 sum of kseq_lengths, 7 max kseq_length, 8 complement of the min non-zero kseq_length)
-
-    // K-rank
-    ev_begin(c, EV_RANK);
-    c->keys_a.alloc(M * sizeof(KeyT)); c->keys_b.alloc(M * sizeof(KeyT));
-    c->vals_a.alloc(M * sizeof(uint32_t)); c->vals_b.alloc(M * sizeof(uint32_t));
-    KeyT *keys_in = c->keys_a.as<KeyT>(), *keys_out = c->keys_b.as<KeyT>();
-    uint32_t *vals_in = c->vals_a.as<uint32_t>(), *vals_out = c->vals_b.as<uint32_t>();
-    if (c->rp.hash_fallback) {
-        if constexpr (sizeof(KeyT) == 8) {
-            hipLaunchKernelGGL(k_rank_hash, dim3((c->N + 255) / 256), dim3(256), 0, st, c->d_res, c->d_off,
-                               c->kmer_off.as<uint64_t>(), c->N, c->rp, keys_in, vals_in);
-        }
-    } else {
-        const uint64_t tiles = (M + RANK_TILE - 1) / RANK_TILE;
-        hipLaunchKernelGGL((k_rank<KeyT>), dim3((uint32_t) tiles), dim3(RANK_THREADS), 0, st, c->d_res, c->d_off,
-                           c->kmer_off.as<uint64_t>(), c->N, M, c->R, c->rp, keys_in, vals_in);
-    }
-    PDL_HIP(hipGetLastError());
-    ev_end(c, EV_RANK);
-
-    // K-sort: stable by rank; gene order of equal ranks is the stream order = ascending gene
-    ev_begin(c, EV_SORT1);
-    pdl_sort_pairs<KeyT>(c, keys_in, keys_out, vals_in, vals_out, M, c->rp.rank_bits);
-    ev_end(c, EV_SORT1);
-    if (!only_complexity) pdl_prepare_tasks(c);     // host work + small uploads while the device sorts
-    // remember which physical buffers hold the sorted stream (pdl_get_dictionary reads them)
-    if ((void *) keys_out != c->keys_b.p) { std::swap(c->keys_a.p, c->keys_b.p); std::swap(c->keys_a.bytes, c->keys_b.bytes); }
-    if ((void *) vals_out != c->vals_b.p) { std::swap(c->vals_a.p, c->vals_b.p); std::swap(c->vals_a.bytes, c->vals_b.bytes); }
-    const KeyT *skeys = c->keys_b.as<KeyT>();
-    const uint32_t *svals = c->vals_b.as<uint32_t>();
-
-    // K-rle
-    ev_begin(c, EV_DICT);
-    c->recpos.alloc((M + 1) * sizeof(uint32_t));
-    c->post.alloc(M * sizeof(uint2));                           // U <= M records (sized before U is known)
-    uint8_t *ghead = reinterpret_cast<uint8_t *>(c->keys_a.p);   // keys_a is free after the sort (>= M bytes)
-    scan_and_apply(c, M, RecHead<KeyT>{skeys, svals},
-                   RecScatter<KeyT>{skeys, svals, M, c->recpos.as<uint32_t>(), c->post.as<uint2>(), ghead}, d_scal + 0);
-    // U (records) and U' (shared records) stay on the device until the end of the build: everything below is sized and
-    // launched for the bound M and reads the counts there — no host round trip in the middle of the pipeline
-    const uint64_t *d_u = d_scal + 0;
-    const uint32_t ublocks = (uint32_t) ((M + 255) / 256);
-    c->gid.alloc(M * sizeof(uint32_t));
-    c->goff.alloc((M + 2) * sizeof(uint32_t));
-    // K-groups
-    scan_and_apply(c, M, GroupHeadFlag{ghead, d_u}, GroupScatter{c->gid.as<uint32_t>(), c->goff.as<uint32_t>(), d_u}, d_scal + 1, nullptr, d_u);
-    hipLaunchKernelGGL(k_fold_last_record, dim3(1), dim3(1024), 0, st, c->post.as<uint2>(), c->recpos.as<uint32_t>(), c->goff.as<uint32_t>(),
-                       d_scal + 1, d_u);
-    PDL_HIP(hipGetLastError());
-    ev_end(c, EV_DICT);
-
-    if (only_complexity) {                   // (cost[] was zeroed by K-len's apply, d_scal[2] with the control block)
-        hipLaunchKernelGGL(k_record_costs, dim3(ublocks), dim3(256), 0, st, c->post.as<uint2>(), c->gid.as<uint32_t>(),
-                           c->goff.as<uint32_t>(), d_u, c->cost.as<unsigned long long>(),
-                           reinterpret_cast<unsigned long long *>(d_scal + 2));
-    } else {
-        // K-ranges
-        ev_begin(c, EV_SORT2);
-        // scratch layout: tuples uint4[M] | v2a u32[M] | k2b u32[M] | v2b u32[M]; key2 lives in vals_a (free after sort 1)
-        c->scratch.alloc(M * (sizeof(uint4) + 3 * sizeof(uint32_t)));
-        uint4 *tuples = c->scratch.as<uint4>();
-        uint32_t *k2a = c->vals_a.as<uint32_t>();
-        uint32_t *v2a = reinterpret_cast<uint32_t *>(tuples + M);
-        uint32_t *k2b = v2a + M;
-        uint32_t *v2b = k2b + M;
-        const uint8_t *in_shard = nullptr;
-        if (!c->dict_shard.empty()) {       // multi-GPU: only the genes this context scores need range lists
-            std::vector<uint8_t> &h = c->h_seq_in_shard;   // lives in the context: the copy below needs no synchronisation
-            h.assign((size_t) c->N, 0);
-            std::vector<uint8_t> gsel((size_t) c->G, 0);
-            for (uint32_t g : c->dict_shard) gsel[g] = 1;
-            for (uint32_t i = 0; i < c->N; i++) h[i] = gsel[c->h_genome_of[i]];
-            c->seq_in_shard.alloc(c->N);
-            PDL_HIP(hipMemcpyAsync(c->seq_in_shard.p, h.data(), c->N, hipMemcpyHostToDevice, st));
-            in_shard = c->seq_in_shard.as<uint8_t>();
-        }
-        const uint32_t upper_only = c->dict_shard.empty() ? 1u : 0u;
-        const SharedScatter scatter{c->post.as<uint2>(), c->gid.as<uint32_t>(), c->goff.as<uint32_t>(), k2a, tuples,
-                                    upper_only, c->cost.as<unsigned long long>()};
-        const uint64_t *d_us = d_scal + 2;       // U' = the scan's total
-        if (upper_only) scan_and_apply(c, M, SharedFlag<true>{c->gid.as<uint32_t>(), c->goff.as<uint32_t>(), c->post.as<uint2>(), nullptr}, scatter, d_scal + 2, nullptr, d_u);
-        else scan_and_apply(c, M, SharedFlag<false>{c->gid.as<uint32_t>(), c->goff.as<uint32_t>(), c->post.as<uint2>(), in_shard}, scatter, d_scal + 2, nullptr, d_u);
-        c->upper_only = upper_only != 0;
-        const uint32_t seq_bits = std::max<uint32_t>(1, bit_length64(c->N ? c->N - 1 : 0));
-        pdl_sort_pairs<uint32_t>(c, k2a, k2b, v2a, v2b, M, seq_bits, true, d_us);     // values = tuple positions; sorted pairs now in (k2b, v2b)
-        ev_end(c, EV_SORT2);
-
-        ev_begin(c, EV_RANGES);
-        c->ranges.alloc(M * sizeof(uint4));
-        c->seq_off.alloc(((size_t) c->N + 1) * sizeof(uint32_t));
-        hipLaunchKernelGGL(k_gather_ranges, dim3(ublocks), dim3(256), 0, st, v2b, k2b, tuples, d_us, c->ranges.as<uint4>(), c->cost.as<unsigned long long>());
-        hipLaunchKernelGGL(k_seq_offsets, dim3((c->N + 1 + 255) / 256), dim3(256), 0, st, k2b, d_us, c->N, c->seq_off.as<uint32_t>());
-        PDL_HIP(hipGetLastError());
-        ev_end(c, EV_RANGES);
-    }
-
-    // K-cost
-    unsigned long long *d_gcost = reinterpret_cast<unsigned long long *>(d_scal + PDL_CTL_GCOST);
-    hipLaunchKernelGGL(k_genome_cost, dim3((c->N + 255) / 256), dim3(256), 0, st, c->cost.as<unsigned long long>(),
-                       c->kseq_len.as<uint32_t>(), c->d_gen, c->N, d_gcost,
-                       reinterpret_cast<unsigned long long *>(d_scal + 4), reinterpret_cast<unsigned long long *>(d_scal + 7),
-                       reinterpret_cast<unsigned long long *>(d_scal + 8));
-
-    uint64_t tail[9] = {0};
-    {
-        PinRead rd(c);                       // one copy: the whole control block
-        const uint64_t *pt = rd.add<uint64_t>(d_scal, PDL_CTL_GCOST + c->G);
-        rd.sync();
-        c->h_genome_cost.assign(pt + PDL_CTL_GCOST, pt + PDL_CTL_GCOST + c->G);
-        memcpy(tail, pt, sizeof(tail));
-    }
-    c->U = tail[0];
-    c->Ushared = tail[2];
-    // every record outside the shared groups is a group of its own: shared groups = all groups - singletons
-    c->NG = c->dict_shard.empty() ? tail[1] - (c->U - c->Ushared) : 0;   // (not counted when only a shard's lists are built)
-    c->sum_kseq = tail[4];
-    c->max_kseq = tail[7];
-    c->min_kseq = tail[8] == 0 ? 1 : ~tail[8];
-    c->P = 0;
-    for (uint64_t v : c->h_genome_cost) c->P += v;
-}
-
-void pdl_run_preprocess(pdl_ctx *c, int kvalue, bool only_complexity) {
+// K-hist + K-len + the rank table; leaves M, the rank parameters and the key width in the context.
+static void stage_alphabet_and_lengths(pdl_ctx *c, int kvalue, bool only_complexity) {
     hipStream_t st = c->stream;
     if (kvalue <= 0) PDL_FAIL(PDL_ERR_KVALUE, "K value must be greater than 0.");
-    ev_begin(c, EV_PRE_TOTAL);
-    // control block: scalars[16] | residue histogram[256] | per-genome cost[G] — one allocation, one clearing fill, and
-    // one device->host copy whenever the host looks (every separate small fill or copy is a dispatch of its own)
-    c->scalars.alloc((PDL_CTL_GCOST + (size_t) c->G) * sizeof(uint64_t));
+    // control block: scalars[16] | residue histogram[256] | per-genome cost[G] (+ [G] lookups above the diagonal, multi-GPU)
+    // — one allocation, one clearing fill, one device->host copy whenever the host looks
+    const size_t ctl_words = PDL_CTL_GCOST + 2 * (size_t) c->G;
+    c->scalars.alloc(ctl_words * sizeof(uint64_t));
     uint64_t *d_scal = c->scalars.as<uint64_t>();
-    PDL_HIP(hipMemsetAsync(d_scal, 0, (PDL_CTL_GCOST + (size_t) c->G) * sizeof(uint64_t), st));
+    PDL_HIP(hipMemsetAsync(d_scal, 0, ctl_words * sizeof(uint64_t), st));
 
-    // K-hist
     ev_begin(c, EV_HIST);
     if (c->R) {
         uint32_t blocks = (uint32_t) std::min<uint64_t>((c->R / 16 + HIST_THREADS - 1) / HIST_THREADS + 1, 256);
@@ -645,27 +628,186 @@ void pdl_run_preprocess(pdl_ctx *c, int kvalue, bool only_complexity) {
     c->kmer_off.alloc(((size_t) c->N + 1) * sizeof(uint64_t));
     c->cost.alloc((size_t) c->N * sizeof(uint64_t));
     scan_and_apply(c, c->N, KseqFlag{c->d_off, (uint32_t) kvalue},
-                   KseqApply{c->kseq_len.as<uint32_t>(), c->kmer_off.as<uint64_t>(), c->cost.as<unsigned long long>()}, d_scal + 5,
-                   c->kmer_off.as<uint64_t>() + c->N);
+                   KseqApply{c->kseq_len.as<uint32_t>(), c->kmer_off.as<uint64_t>(), c->cost.as<unsigned long long>(), c->d_off, c->R,
+                             reinterpret_cast<unsigned long long *>(d_scal + 3)}, d_scal + 5, c->kmer_off.as<uint64_t>() + c->N);
     uint64_t counters[256];
-    uint64_t M = 0;
+    uint64_t M = 0, bad = 0;
     {
         PinRead rd(c);
         const uint64_t *pc = rd.add<uint64_t>(d_scal, PDL_CTL_GCOST);          // scalars + histogram in one copy
         ev_end(c, EV_HIST);
         rd.sync();
         memcpy(counters, pc + PDL_CTL_HIST, sizeof(counters));
-        M = pc[5];
+        M = pc[5]; bad = pc[3];
     }
-
+    if (bad) PDL_FAIL(PDL_ERR_ARGUMENT, "offsets must ascend from 0 to the residue count (%llu)", (unsigned long long) c->R);
     rank_init_host(c->rp, counters, kvalue);
     c->M = M;
     c->only_complexity = only_complexity;
     if (M == 0) PDL_FAIL(PDL_ERR_EMPTY, "no gene is at least k=%d residues long: the dictionary is empty", kvalue);
     // the scan above sums in 32 bits: make sure it cannot have wrapped, and keep stream positions in u32
     if (c->R >= 0xfffffff0ull) PDL_FAIL(PDL_ERR_UNSUPPORTED, "more than 2^32 residues (%llu) need 64-bit stream positions", (unsigned long long) c->R);
-
     c->key64 = c->rp.rank_bits > 32;
+}
+
+// K-rank over the whole stream into (keys_a, vals_a)
+template <class KeyT>
+static void stage_rank(pdl_ctx *c) {
+    hipStream_t st = c->stream;
+    const uint64_t M = c->M;
+    c->keys_a.alloc(M * sizeof(KeyT)); c->keys_b.alloc(M * sizeof(KeyT));
+    c->vals_a.alloc(M * sizeof(uint32_t)); c->vals_b.alloc(M * sizeof(uint32_t));
+    if (c->rp.hash_fallback) {
+        if constexpr (sizeof(KeyT) == 8) {
+            hipLaunchKernelGGL(k_rank_hash<0>, dim3((c->N + 255) / 256), dim3(256), 0, st, c->d_res, c->d_off,
+                               c->kmer_off.as<uint64_t>(), c->N, c->rp, c->keys_a.as<uint64_t>(), c->vals_a.as<uint32_t>(), (uint32_t *) nullptr);
+        }
+    } else {
+        const uint64_t tiles = (M + RANK_TILE - 1) / RANK_TILE;
+        hipLaunchKernelGGL((k_rank<KeyT, 0>), dim3((uint32_t) tiles), dim3(RANK_THREADS), 0, st, c->d_res, c->d_off,
+                           c->kmer_off.as<uint64_t>(), c->N, M, c->R, c->rp, c->keys_a.as<KeyT>(), c->vals_a.as<uint32_t>(), 0u, (uint32_t *) nullptr);
+    }
+    PDL_HIP(hipGetLastError());
+}
+
+// K-sort + K-rle over the first m elements of (keys_in, vals_in): records into c->post / recpos / ghead (in keys_a).
+// d_scal[0] receives the record count.
+template <class KeyT>
+static void stage_sort_and_dedup(pdl_ctx *c, KeyT *keys_in, KeyT *keys_out, uint32_t *vals_in, uint32_t *vals_out, uint64_t m, bool pack_head) {
+    uint64_t *d_scal = c->scalars.as<uint64_t>();
+    ev_begin(c, EV_SORT1);
+    pdl_sort_pairs<KeyT>(c, keys_in, keys_out, vals_in, vals_out, m, c->rp.rank_bits);
+    ev_end(c, EV_SORT1);
+    // remember which physical buffers hold the sorted stream (pdl_get_dictionary reads them)
+    if ((void *) keys_out != c->keys_b.p) { std::swap(c->keys_a.p, c->keys_b.p); std::swap(c->keys_a.bytes, c->keys_b.bytes); }
+    if ((void *) vals_out != c->vals_b.p) { std::swap(c->vals_a.p, c->vals_b.p); std::swap(c->vals_a.bytes, c->vals_b.bytes); }
+    const KeyT *skeys = c->keys_b.as<KeyT>();
+    const uint32_t *svals = c->vals_b.as<uint32_t>();
+    ev_begin(c, EV_DICT);                                       // (ended by the caller, behind K-groups where it runs them)
+    c->recpos.alloc((m + 1) * sizeof(uint32_t));
+    c->post.alloc(m * sizeof(uint2));                           // U <= m records (sized before U is known)
+    uint8_t *ghead = reinterpret_cast<uint8_t *>(c->keys_a.p);   // keys_a is free after the sort (>= m bytes)
+    scan_and_apply(c, m, RecHead<KeyT>{skeys, svals},
+                   RecScatter<KeyT>{skeys, svals, m, c->recpos.as<uint32_t>(), c->post.as<uint2>(), ghead, pack_head ? 1u : 0u}, d_scal + 0);
+}
+
+// K-ranges + K-cost over the grouped dictionary (post/gid/goff hold `bound` records at most, the count is at d_scal[0]).
+//   mode 0: whole groups for the shard's genes | 1: upper ranges, every gene | 2: upper ranges, the shard's genes
+static void stage_ranges_and_costs(pdl_ctx *c, uint64_t bound, int mode, bool only_complexity) {
+    hipStream_t st = c->stream;
+    uint64_t *d_scal = c->scalars.as<uint64_t>();
+    const uint64_t *d_u = d_scal + 0;
+    uint2 *post = pdl_postings(c);
+    const uint32_t ublocks = (uint32_t) ((bound + 255) / 256);
+    if (only_complexity) {                   // (cost[] was zeroed by K-len's apply, d_scal[2] with the control block)
+        hipLaunchKernelGGL(k_record_costs, dim3(ublocks), dim3(256), 0, st, post, c->gid.as<uint32_t>(),
+                           c->goff.as<uint32_t>(), d_u, c->cost.as<unsigned long long>(),
+                           reinterpret_cast<unsigned long long *>(d_scal + 2));
+    } else {
+        ev_begin(c, EV_SORT2);
+        // scratch layout: tuples uint4[bound] | v2a u32[bound] | k2b u32[bound] | v2b u32[bound]; key2 lives in vals_a (free after sort 1)
+        c->scratch.alloc(bound * (sizeof(uint4) + 3 * sizeof(uint32_t)));
+        c->vals_a.alloc(bound * sizeof(uint32_t));
+        uint4 *tuples = c->scratch.as<uint4>();
+        uint32_t *k2a = c->vals_a.as<uint32_t>();
+        uint32_t *v2a = reinterpret_cast<uint32_t *>(tuples + bound);
+        uint32_t *k2b = v2a + bound;
+        uint32_t *v2b = k2b + bound;
+        const uint8_t *in_shard = nullptr;
+        if (mode != 1) {                    // only the genes this context scores need range lists
+            std::vector<uint8_t> &h = c->h_seq_in_shard;   // lives in the context: the copy below needs no synchronisation
+            h.assign((size_t) c->N, 0);
+            std::vector<uint8_t> gsel((size_t) c->G, 0);
+            for (uint32_t g : c->dict_shard) gsel[g] = 1;
+            for (uint32_t i = 0; i < c->N; i++) h[i] = gsel[c->h_genome_of[i]];
+            c->seq_in_shard.alloc(c->N);
+            PDL_HIP(hipMemcpyAsync(c->seq_in_shard.p, h.data(), c->N, hipMemcpyHostToDevice, st));
+            in_shard = c->seq_in_shard.as<uint8_t>();
+        }
+        const uint32_t upper_only = mode == 0 ? 0u : 1u;
+        const SharedScatter scatter{post, c->gid.as<uint32_t>(), c->goff.as<uint32_t>(), k2a, tuples,
+                                    upper_only, c->cost.as<unsigned long long>(), in_shard};
+        const uint64_t *d_us = d_scal + 2;       // ranges built = the scan's total
+        const uint32_t *gid = c->gid.as<uint32_t>(), *goff = c->goff.as<uint32_t>();
+        if (mode == 1) scan_and_apply(c, bound, SharedFlag<1>{gid, goff, post, nullptr}, scatter, d_scal + 2, nullptr, d_u);
+        else if (mode == 2) scan_and_apply(c, bound, SharedFlag<2>{gid, goff, post, in_shard}, scatter, d_scal + 2, nullptr, d_u);
+        else scan_and_apply(c, bound, SharedFlag<0>{gid, goff, post, in_shard}, scatter, d_scal + 2, nullptr, d_u);
+        c->upper_only = upper_only != 0;
+        const uint32_t seq_bits = std::max<uint32_t>(1, bit_length64(c->N ? c->N - 1 : 0));
+        pdl_sort_pairs<uint32_t>(c, k2a, k2b, v2a, v2b, bound, seq_bits, true, d_us);     // values = tuple positions; sorted pairs now in (k2b, v2b)
+        ev_end(c, EV_SORT2);
+
+        ev_begin(c, EV_RANGES);
+        c->ranges.alloc(bound * sizeof(uint4));
+        c->seq_off.alloc(((size_t) c->N + 1) * sizeof(uint32_t));
+        hipLaunchKernelGGL(k_gather_ranges, dim3(ublocks), dim3(256), 0, st, v2b, k2b, tuples, d_us, c->ranges.as<uint4>(), c->cost.as<unsigned long long>());
+        hipLaunchKernelGGL(k_seq_offsets, dim3((c->N + 1 + 255) / 256), dim3(256), 0, st, k2b, d_us, c->N, c->seq_off.as<uint32_t>());
+        PDL_HIP(hipGetLastError());
+        ev_end(c, EV_RANGES);
+    }
+
+    // K-cost; U' and the number of shared groups over the whole dictionary (one light pass over gid/goff; the multi-GPU
+    // build has them already from its per-genome pass)
+    unsigned long long *d_gcost = reinterpret_cast<unsigned long long *>(d_scal + PDL_CTL_GCOST);
+    hipLaunchKernelGGL(k_genome_cost, dim3((c->N + 255) / 256), dim3(256), 0, st, c->cost.as<unsigned long long>(),
+                       c->kseq_len.as<uint32_t>(), c->d_gen, c->N, d_gcost,
+                       reinterpret_cast<unsigned long long *>(d_scal + 4), reinterpret_cast<unsigned long long *>(d_scal + 7),
+                       reinterpret_cast<unsigned long long *>(d_scal + 8));
+    if (!c->dist)
+        hipLaunchKernelGGL(k_dictionary_counters<false>, dim3((uint32_t) std::min<uint64_t>(ublocks, 1024)), dim3(256), 0, st, post, c->gid.as<uint32_t>(),
+                           c->goff.as<uint32_t>(), d_u, (const uint32_t *) nullptr, 0u, reinterpret_cast<unsigned long long *>(d_scal + 10),
+                           (unsigned long long *) nullptr, (unsigned long long *) nullptr);
+    PDL_HIP(hipGetLastError());
+
+    uint64_t tail[12] = {0};
+    {
+        PinRead rd(c);                       // one copy: the whole control block
+        const uint64_t *pt = rd.add<uint64_t>(d_scal, PDL_CTL_GCOST + c->G);
+        rd.sync();
+        if (!c->dist) c->h_genome_cost.assign(pt + PDL_CTL_GCOST, pt + PDL_CTL_GCOST + c->G);     // (multi-GPU: every genome's cost is known already)
+        memcpy(tail, pt, sizeof(tail));
+    }
+    c->U = tail[0];
+    c->Ushared = tail[10];
+    c->NG = tail[11];
+    c->sum_kseq = tail[4];
+    c->max_kseq = tail[7];
+    c->min_kseq = tail[8] == 0 ? 1 : ~tail[8];
+    c->P = 0;
+    for (uint64_t v : c->h_genome_cost) c->P += v;
+}
+
+template <class KeyT>
+static void dictionary_pipeline(pdl_ctx *c, bool only_complexity) {
+    hipStream_t st = c->stream;
+    const uint64_t M = c->M;
+    uint64_t *d_scal = c->scalars.as<uint64_t>();
+    ev_begin(c, EV_RANK);
+    stage_rank<KeyT>(c);
+    ev_end(c, EV_RANK);
+    KeyT *keys_in = c->keys_a.as<KeyT>(), *keys_out = c->keys_b.as<KeyT>();
+    uint32_t *vals_in = c->vals_a.as<uint32_t>(), *vals_out = c->vals_b.as<uint32_t>();
+    stage_sort_and_dedup<KeyT>(c, keys_in, keys_out, vals_in, vals_out, M, false);
+    if (!only_complexity) pdl_prepare_tasks(c);     // host work + small uploads while the device sorts
+    // U (records) and the range count stay on the device until the end of the build: everything below is sized and
+    // launched for the bound M and reads the counts there — no host round trip in the middle of the pipeline
+    const uint64_t *d_u = d_scal + 0;
+    c->gid.alloc(M * sizeof(uint32_t));
+    c->goff.alloc((M + 2) * sizeof(uint32_t));
+    const uint8_t *ghead = reinterpret_cast<const uint8_t *>(c->keys_a.p);
+    scan_and_apply(c, M, GroupHeadFlag{ghead, d_u}, GroupScatter{c->gid.as<uint32_t>(), c->goff.as<uint32_t>(), d_u}, d_scal + 1, nullptr, d_u);
+    hipLaunchKernelGGL(k_fold_last_record, dim3(1), dim3(1024), 0, st, c->post.as<uint2>(), c->recpos.as<uint32_t>(), c->goff.as<uint32_t>(),
+                       d_scal + 1, d_u);
+    PDL_HIP(hipGetLastError());
+    ev_end(c, EV_DICT);
+    stage_ranges_and_costs(c, M, c->dict_shard.empty() ? 1 : 0, only_complexity);
+}
+
+void pdl_run_preprocess(pdl_ctx *c, int kvalue, bool only_complexity) {
+    hipStream_t st = c->stream;
+    ev_begin(c, EV_PRE_TOTAL);
+    c->dist = false; c->dist_stage = 0; c->post_ext = nullptr;
+    stage_alphabet_and_lengths(c, kvalue, only_complexity);
     if (c->key64) dictionary_pipeline<uint64_t>(c, only_complexity);
     else dictionary_pipeline<uint32_t>(c, only_complexity);
     ev_end(c, EV_PRE_TOTAL);
@@ -677,4 +819,168 @@ void pdl_run_preprocess(pdl_ctx *c, int kvalue, bool only_complexity) {
     c->tm.sort_seq_ms = only_complexity ? 0.f : ev_ms(c, EV_SORT2);
     c->tm.ranges_ms = only_complexity ? 0.f : ev_ms(c, EV_RANGES);
     c->tm.preprocess_total_ms = ev_ms(c, EV_PRE_TOTAL);
+    c->tm.dist_begin_ms = c->tm.dist_finish_ms = 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Multi-GPU build (include/pandelos_amd.h, pdl_dist_*).  Every GPU ranks all k-mers (the input is shared), keeps the
+// ones of its rank interval, and sorts + dedups those: its run of the dictionary.  The caller all-gathers the runs; the
+// concatenation in rank order is the dictionary of library.cpp:270-287, so no merge is needed.
+// ------------------------------------------------------------------------------------------------
+template <class KeyT>
+static void dist_slice_pipeline(pdl_ctx *c) {
+    hipStream_t st = c->stream;
+    const uint64_t M = c->M;
+    uint64_t *d_scal = c->scalars.as<uint64_t>();
+    const uint32_t W = c->world, me = c->rank;
+    // 1. k-mers per bin of the rank space (top DIST_BIN_BITS bits of a rank)
+    ev_begin(c, EV_RANK);
+    const uint32_t shift = c->rp.rank_bits > DIST_BIN_BITS ? c->rp.rank_bits - DIST_BIN_BITS : 0;
+    c->scratch2.alloc(std::max<size_t>(c->scratch2.bytes, DIST_BINS * sizeof(uint32_t)));
+    uint32_t *d_bins = c->scratch2.as<uint32_t>();
+    PDL_HIP(hipMemsetAsync(d_bins, 0, DIST_BINS * sizeof(uint32_t), st));
+    c->keys_a.alloc(M * sizeof(KeyT));
+    if (c->rp.hash_fallback) {
+        if constexpr (sizeof(KeyT) == 8)
+            hipLaunchKernelGGL(k_rank_hash<1>, dim3((c->N + 255) / 256), dim3(256), 0, st, c->d_res, c->d_off, c->kmer_off.as<uint64_t>(), c->N,
+                               c->rp, (uint64_t *) nullptr, (uint32_t *) nullptr, d_bins);
+    } else {
+        const uint64_t tiles = (M + RANK_TILE - 1) / RANK_TILE;
+        hipLaunchKernelGGL((k_rank<KeyT, 1>), dim3((uint32_t) std::min<uint64_t>(tiles, 1024)), dim3(RANK_THREADS), 0, st, c->d_res, c->d_off,
+                           c->kmer_off.as<uint64_t>(), c->N, M, c->R, c->rp, (KeyT *) nullptr, (uint32_t *) nullptr, shift, d_bins);
+    }
+    PDL_HIP(hipGetLastError());
+    // 2. the ranks themselves (queued behind the count; the host reads the bins meanwhile)
+    stage_rank<KeyT>(c);
+    ev_end(c, EV_RANK);
+    std::vector<uint64_t> pre(DIST_BINS + 1, 0);
+    {
+        PinRead rd(c);
+        const uint32_t *pb = rd.add<uint32_t>(d_bins, DIST_BINS);
+        rd.sync();
+        for (uint32_t b = 0; b < DIST_BINS; b++) pre[b + 1] = pre[b] + pb[b];
+    }
+    if (pre[DIST_BINS] != M) PDL_FAIL(PDL_ERR_DEVICE, "interval histogram counts %llu k-mers, the stream holds %llu", (unsigned long long) pre[DIST_BINS], (unsigned long long) M);
+    // cut w = first bin whose exclusive prefix reaches w * M / W: the same on every rank (function of the input only)
+    auto cut = [&](uint32_t w) -> uint32_t {
+        if (w == 0) return 0;
+        if (w >= W) return DIST_BINS;
+        const uint64_t target = (uint64_t) ((unsigned __int128) M * w / W);
+        return (uint32_t) (std::lower_bound(pre.begin(), pre.end() - 1, target) - pre.begin());
+    };
+    const uint32_t b_lo = cut(me), b_hi = cut(me + 1);
+    const uint64_t m_own = pre[b_hi] - pre[b_lo];
+    c->M_slice = m_own;
+    // 3. this rank's k-mers, in stream order (the sort below is stable: equal ranks keep ascending gene order)
+    KeyT *sel_k = c->keys_b.as<KeyT>();
+    uint32_t *sel_v = c->vals_b.as<uint32_t>();
+    scan_and_apply(c, M, SelFlag<KeyT>{c->keys_a.as<KeyT>(), shift, b_lo, b_hi},
+                   SelApply<KeyT>{c->keys_a.as<KeyT>(), c->vals_a.as<uint32_t>(), sel_k, sel_v}, d_scal + 15);
+    // 4. sort + dedup 1/W of the stream; the group-head flag rides in bit 31 of the count
+    c->U_slice = 0;
+    if (m_own) {
+        KeyT *keys_in = sel_k, *keys_out = c->keys_a.as<KeyT>();
+        uint32_t *vals_in = sel_v, *vals_out = c->vals_a.as<uint32_t>();
+        stage_sort_and_dedup<KeyT>(c, keys_in, keys_out, vals_in, vals_out, m_own, true);
+        ev_end(c, EV_DICT);
+    } else {
+        c->post.alloc(16);
+    }
+}
+
+void pdl_run_dist_begin(pdl_ctx *c, int kvalue) {
+    hipStream_t st = c->stream;
+    ev_begin(c, EV_PRE_TOTAL);
+    ev_begin(c, EV_DIST_BEGIN);
+    c->dist = true; c->dist_stage = 0; c->post_ext = nullptr;
+    stage_alphabet_and_lengths(c, kvalue, false);
+    if (c->key64) dist_slice_pipeline<uint64_t>(c); else dist_slice_pipeline<uint32_t>(c);
+    ev_end(c, EV_DIST_BEGIN);
+    if (c->M_slice) {
+        PinRead rd(c);
+        const uint64_t *pu = rd.add<uint64_t>(c->scalars.as<uint64_t>(), 1);
+        rd.sync();
+        c->U_slice = pu[0];
+    } else {
+        PDL_HIP(hipStreamSynchronize(st));
+    }
+    c->tm.hist_ms = ev_ms(c, EV_HIST);
+    c->tm.rank_ms = ev_ms(c, EV_RANK);
+    c->tm.sort_rank_ms = c->M_slice ? ev_ms(c, EV_SORT1) : 0.f;
+    c->tm.dict_ms = c->M_slice ? ev_ms(c, EV_DICT) : 0.f;
+    c->tm.dist_begin_ms = ev_ms(c, EV_DIST_BEGIN);
+    c->dist_stage = 1;
+}
+
+// longest-processing-time assignment, deterministic (ties: lower genome id first, then lower rank)
+static void lpt_owner(const std::vector<uint64_t> &w, uint32_t world, std::vector<uint32_t> &owner) {
+    const uint32_t G = (uint32_t) w.size();
+    std::vector<uint32_t> order(G);
+    for (uint32_t g = 0; g < G; g++) order[g] = g;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return w[a] > w[b]; });
+    std::vector<uint64_t> load(world, 0);
+    owner.assign(G, 0);
+    for (uint32_t g : order) {
+        uint32_t best = 0;
+        for (uint32_t r = 1; r < world; r++) if (load[r] < load[best]) best = r;
+        owner[g] = best;
+        load[best] += w[g] + 1;          // (+1: genomes without any lookup still spread over the ranks)
+    }
+}
+
+void pdl_run_dist_finish(pdl_ctx *c, uint64_t total) {
+    hipStream_t st = c->stream;
+    uint64_t *d_scal = c->scalars.as<uint64_t>();
+    ev_begin(c, EV_DIST_FINISH);
+    if (total == 0) PDL_FAIL(PDL_ERR_EMPTY, "empty dictionary");
+    if (total >= 0xfffff000ull) PDL_FAIL(PDL_ERR_UNSUPPORTED, "a dictionary of %llu records needs 64-bit record indices", (unsigned long long) total);
+    uint2 *post = c->post_ext;
+    // the record count of the whole dictionary goes where the kernels expect it (d_scal[0]); the other counters restart
+    uint64_t *h_u = reinterpret_cast<uint64_t *>(c->pin);       // (pinned scratch; rewritten only by the next PinRead, which comes after a sync)
+    if (!h_u) PDL_FAIL(PDL_ERR_DEVICE, "pinned scratch missing");
+    h_u[0] = total;
+    PDL_HIP(hipMemcpyAsync(d_scal + 0, h_u, sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    PDL_HIP(hipMemsetAsync(d_scal + 1, 0, 2 * sizeof(uint64_t), st));
+    PDL_HIP(hipMemsetAsync(d_scal + 9, 0, 3 * sizeof(uint64_t), st));
+    const uint64_t *d_u = d_scal + 0;
+    // K-groups over the gathered runs (library.cpp:289-335, the fold of the last record included)
+    c->gid.alloc(total * sizeof(uint32_t));
+    c->goff.alloc((total + 2) * sizeof(uint32_t));
+    scan_and_apply(c, total, GroupHeadFlagPacked{post, d_u}, GroupScatterStrip{c->gid.as<uint32_t>(), c->goff.as<uint32_t>(), d_u, post}, d_scal + 1);
+    hipLaunchKernelGGL(k_fold_last_record, dim3(1), dim3(1024), 0, st, post, (uint32_t *) nullptr, c->goff.as<uint32_t>(), d_scal + 1, d_u);
+    // every genome's lookups (the reference's count, and above the diagonal), U', shared groups
+    unsigned long long *d_full = reinterpret_cast<unsigned long long *>(d_scal + PDL_CTL_GCOST) + c->G;      // [G] behind the K-cost block
+    c->scratch2.alloc(std::max<size_t>(c->scratch2.bytes, 2 * (size_t) c->G * sizeof(uint64_t)));
+    unsigned long long *d_upper = c->scratch2.as<unsigned long long>();
+    PDL_HIP(hipMemsetAsync(d_upper, 0, (size_t) c->G * sizeof(uint64_t), st));
+    const uint32_t ublocks = (uint32_t) std::min<uint64_t>((total + 255) / 256, 1024);
+    hipLaunchKernelGGL(k_dictionary_counters<true>, dim3(ublocks), dim3(256), 0, st, post, c->gid.as<uint32_t>(), c->goff.as<uint32_t>(), d_u,
+                       c->d_gen, c->G, reinterpret_cast<unsigned long long *>(d_scal + 10), d_full, d_upper);
+    PDL_HIP(hipGetLastError());
+    c->h_upper_cost.assign(c->G, 0);
+    {
+        PinRead rd(c);
+        const uint64_t *pf = rd.add<uint64_t>(d_full, c->G);
+        const uint64_t *pu = rd.add<uint64_t>(d_upper, c->G);
+        rd.sync();
+        c->h_genome_cost.assign(pf, pf + c->G);
+        c->h_upper_cost.assign(pu, pu + c->G);
+    }
+    // genomes -> ranks; this rank's shard
+    lpt_owner(c->h_upper_cost, c->world, c->h_owner);
+    c->shard.clear();
+    for (uint32_t g = 0; g < c->G; g++) if (c->h_owner[g] == c->rank) c->shard.push_back(g);
+    c->shard_set = true;
+    c->dict_shard = c->shard;
+    c->tasks_ready = false;
+    pdl_prepare_tasks(c);
+    stage_ranges_and_costs(c, total, 2, false);
+    ev_end(c, EV_DIST_FINISH);
+    ev_end(c, EV_PRE_TOTAL);
+    PDL_HIP(hipStreamSynchronize(st));
+    c->tm.sort_seq_ms = ev_ms(c, EV_SORT2);
+    c->tm.ranges_ms = ev_ms(c, EV_RANGES);
+    c->tm.dist_finish_ms = ev_ms(c, EV_DIST_FINISH);
+    c->tm.preprocess_total_ms = c->tm.dist_begin_ms + c->tm.dist_finish_ms;
+    c->dist_stage = 2;
 }

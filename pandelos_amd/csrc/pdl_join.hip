@@ -57,7 +57,8 @@ struct JoinArgs {
     uint32_t *st_col, *st_first;
     uint32_t *st_src;              // mirror mode: gene id of the row that produced the staged cell
     uint32_t mirror;               // 1: ranges hold only columns above the row; every cell (r,c) also stands for (c,r)
-    const uint32_t *taskpos_of;    // mirror mode: task position of every gene
+    const uint32_t *taskpos_of;    // mirror mode: task position of every gene (0xffffffff: the gene is another GPU's row)
+    const uint32_t *local_genome;  // mirror mode: index of every genome in this context's shard (CM row)
     uint32_t *mirror_cnt;          // mirror mode: mirrored cells per task position
     unsigned long long st_cap;
     uint32_t *work_cursor;         // persistent-workgroup row dispenser (one atomic hands out `work_batch` items:
@@ -480,12 +481,15 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ == 10) ? 5 : 1) void k_join
                     atomicMax(reinterpret_cast<uint32_t *>(cm_row + c), __float_as_uint(score));
                     if (a.mirror) {
                         // the same sums seen from gene c: cell (c, r) with perc and tr_perc swapped (both quotients
-                        // use the same integers the row program of c would have summed); K-order places it in c's row
+                        // use the same integers the row program of c would have summed); K-order places it in c's row.
+                        // Multi-GPU: when c is another GPU's row the staged cell travels there (k_outbox_*).
                         const uint32_t pc = a.taskpos_of[c];
                         a.st_src[o] = r;
-                        atomicAdd(&a.mirror_cnt[pc], 1u);
-                        atomicMax(reinterpret_cast<uint32_t *>(a.MS + (size_t) pc * a.G + my_genome), __float_as_uint(score));
-                        atomicMax(reinterpret_cast<uint32_t *>(a.CM + (size_t) gc * a.N + r), __float_as_uint(score));
+                        if (pc != 0xffffffffu) {
+                            atomicAdd(&a.mirror_cnt[pc], 1u);
+                            atomicMax(reinterpret_cast<uint32_t *>(a.MS + (size_t) pc * a.G + my_genome), __float_as_uint(score));
+                            atomicMax(reinterpret_cast<uint32_t *>(a.CM + (size_t) a.local_genome[gc] * a.N + r), __float_as_uint(score));
+                        }
                     }
                 }
             }
@@ -493,8 +497,9 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ == 10) ? 5 : 1) void k_join
         __syncthreads();
         if (tid == 0) {
             const uint32_t nemit = s_nemit;
-            a.row_base[p] = (uint32_t) base;
-            a.row_cnt[p] = nemit;
+            a.row_base[p] = fits ? (uint32_t) base : 0u;
+            a.row_cnt[p] = fits ? nemit : 0u;       // staging ran out: the row holds nothing (the host repeats the pass with the
+                                                    // size asked for); everything queued behind the join stays inside its buffers
             s_chunk_next = base + nemit;
             s_ntouched = 0; s_nemit = 0; s_next = next_reg; s_desc = next_desc;
         }
@@ -591,8 +596,9 @@ __global__ __launch_bounds__(HBM_THREADS) void k_join_hbm(JoinArgs a) {
         if (tid == 0) {
             const unsigned long long base = atomicAdd(a.cell_cursor, (unsigned long long) nemit);
             s_base = base;
-            a.row_base[p] = (uint32_t) base;
-            a.row_cnt[p] = nemit;
+            const bool fits = base + nemit <= a.st_cap;     // else: nothing is staged, the host repeats the pass
+            a.row_base[p] = fits ? (uint32_t) base : 0u;
+            a.row_cnt[p] = fits ? nemit : 0u;
         }
         __syncthreads();
         const unsigned long long base = s_base;
@@ -612,9 +618,11 @@ __global__ __launch_bounds__(HBM_THREADS) void k_join_hbm(JoinArgs a) {
                 if (a.mirror) {      // cell (c, r), see k_join_lds
                     const uint32_t pc = a.taskpos_of[c];
                     a.st_src[o] = r;
-                    atomicAdd(&a.mirror_cnt[pc], 1u);
-                    atomicMax(reinterpret_cast<uint32_t *>(a.MS + (size_t) pc * a.G + a.genome_of[r]), __float_as_uint(score));
-                    atomicMax(reinterpret_cast<uint32_t *>(a.CM + (size_t) gc * a.N + r), __float_as_uint(score));
+                    if (pc != 0xffffffffu) {
+                        atomicAdd(&a.mirror_cnt[pc], 1u);
+                        atomicMax(reinterpret_cast<uint32_t *>(a.MS + (size_t) pc * a.G + a.genome_of[r]), __float_as_uint(score));
+                        atomicMax(reinterpret_cast<uint32_t *>(a.CM + (size_t) a.local_genome[gc] * a.N + r), __float_as_uint(score));
+                    }
                 }
             }
         }
@@ -837,8 +845,90 @@ __global__ __launch_bounds__(256) void k_mirror_refs(const uint32_t *__restrict_
     const uint32_t base = row_base[p], cnt = row_cnt[p];
     for (uint32_t i = threadIdx.x & (PDL_WAVE - 1); i < cnt; i += PDL_WAVE) {
         const uint32_t pc = taskpos_of[st_col[base + i]];
-        mirror_ref[mirror_off[pc] + atomicAdd(&mirror_cur[pc], 1u)] = base + i;
+        if (pc != 0xffffffffu) mirror_ref[mirror_off[pc] + atomicAdd(&mirror_cur[pc], 1u)] = base + i;     // (else: another GPU's row)
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Multi-GPU cell exchange.  A staged cell (r, c) whose column c is a row of another GPU is listed for that GPU
+// (pdl_dist_cell), grouped by destination: a counting pass and a scattering pass over the staged cells with the same
+// rows -> workgroup assignment (LDS counters per destination, no global atomics), an exclusive scan in between.
+// The receiver files the cells behind its own staged cells (slot = st_local + i) as mirrored cells of row c.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t PDL_MAX_WORLD = 64;
+struct OutboxArgs {
+    const uint32_t *row_base, *row_cnt, *task_rows;
+    const float *st_score, *st_perc, *st_tr;
+    const uint32_t *st_col, *st_first;
+    const uint32_t *taskpos_of, *genome_of, *owner;
+    uint32_t n_rows, rows_per_block, world, n_blocks;
+    uint32_t *tab;                 // [world][n_blocks]: counts (pass 1), then their exclusive scan (pass 2 reads `offs`)
+    const uint32_t *offs;
+    pdl_dist_cell *out;
+};
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void k_outbox(OutboxArgs a) {
+    __shared__ uint32_t s_cnt[PDL_MAX_WORLD];
+    if (threadIdx.x < PDL_MAX_WORLD) s_cnt[threadIdx.x] = SCATTER && threadIdx.x < a.world ? a.offs[(size_t) threadIdx.x * a.n_blocks + blockIdx.x] : 0u;
+    __syncthreads();
+    const uint32_t p0 = blockIdx.x * a.rows_per_block, p1 = min(a.n_rows, p0 + a.rows_per_block);
+    const uint32_t lane = threadIdx.x & (PDL_WAVE - 1);
+    for (uint32_t p = p0 + threadIdx.x / PDL_WAVE; p < p1; p += 256 / PDL_WAVE) {
+        const uint32_t base = a.row_base[p], cnt = a.row_cnt[p];
+        for (uint32_t i = lane; i < cnt; i += PDL_WAVE) {
+            const uint32_t col = a.st_col[base + i];
+            if (a.taskpos_of[col] != 0xffffffffu) continue;
+            const uint32_t d = a.owner[a.genome_of[col]];
+            const uint32_t at = atomicAdd(&s_cnt[d], 1u);
+            if constexpr (SCATTER)
+                a.out[at] = pdl_dist_cell{a.st_score[base + i], a.st_perc[base + i], a.st_tr[base + i], a.task_rows[p], col, a.st_first[base + i]};
+        }
+    }
+    if constexpr (!SCATTER) {
+        __syncthreads();
+        if (threadIdx.x < a.world) a.tab[(size_t) threadIdx.x * a.n_blocks + blockIdx.x] = s_cnt[threadIdx.x];
+    }
+}
+// first cell of every destination's list + the total, for the host: dst[d] = offs[d][0], dst[world] = total
+__global__ void k_outbox_totals(const uint32_t *offs, uint32_t n_blocks, uint32_t world, const uint64_t *d_total, uint32_t *dst) {
+    const uint32_t d = threadIdx.x;
+    if (d < world) dst[d] = offs[(size_t) d * n_blocks];
+    else if (d == world) dst[d] = (uint32_t) *d_total;
+}
+
+struct InboxArgs {
+    const pdl_dist_cell *in; uint32_t n, slot0;
+    float *st_score, *st_perc, *st_tr;
+    uint32_t *st_col, *st_first, *st_src;
+    const uint32_t *taskpos_of, *genome_of, *local_genome;
+    uint32_t *mirror_cnt;
+    float *MS, *CM;
+    uint32_t N, G;
+    uint32_t *error_count;
+};
+// a received cell (r, c): staged like a local one, counted for row c and folded into c's maxima (library.cpp:513-515
+// seen from row c: its column is r)
+__global__ __launch_bounds__(256) void k_inbox_file(InboxArgs a) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const pdl_dist_cell cl = a.in[i];
+    if (cl.column >= a.N || cl.row >= a.N) { atomicAdd(a.error_count, 1u); return; }
+    const uint32_t pc = a.taskpos_of[cl.column];
+    const uint32_t slot = a.slot0 + i;
+    a.st_score[slot] = cl.score; a.st_perc[slot] = cl.perc; a.st_tr[slot] = cl.tr_perc;
+    a.st_col[slot] = cl.column; a.st_src[slot] = cl.row; a.st_first[slot] = cl.first_group;
+    if (pc == 0xffffffffu) { atomicAdd(a.error_count, 1u); return; }      // not a row of this GPU: the exchange went wrong
+    atomicAdd(&a.mirror_cnt[pc], 1u);
+    atomicMax(reinterpret_cast<uint32_t *>(a.MS + (size_t) pc * a.G + a.genome_of[cl.row]), __float_as_uint(cl.score));
+    atomicMax(reinterpret_cast<uint32_t *>(a.CM + (size_t) a.local_genome[a.genome_of[cl.column]] * a.N + cl.row), __float_as_uint(cl.score));
+}
+__global__ __launch_bounds__(256) void k_mirror_refs_inbox(const uint32_t *__restrict__ st_col, const uint32_t *__restrict__ taskpos_of,
+                                                           const uint32_t *__restrict__ mirror_off, uint32_t *__restrict__ mirror_cur,
+                                                           uint32_t slot0, uint32_t n, uint32_t *__restrict__ mirror_ref) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t pc = taskpos_of[st_col[slot0 + i]];
+    if (pc != 0xffffffffu) mirror_ref[mirror_off[pc] + atomicAdd(&mirror_cur[pc], 1u)] = slot0 + i;
 }
 
 // work-item descriptors of the LDS join, in processing order (currently task order)
@@ -918,57 +1008,56 @@ void pdl_prepare_tasks(pdl_ctx *c) {
     c->h_task_row_off[S] = n_rows;
     c->n_task_rows = n_rows;
     c->tasks_ready = true;
-    if (n_rows == 0) return;
-    c->task_rows.alloc((size_t) n_rows * 4); c->task_lg.alloc((size_t) n_rows * 4);
-    PDL_HIP(hipMemcpyAsync(c->task_rows.p, c->h_task_rows_host.data(), (size_t) n_rows * 4, hipMemcpyHostToDevice, st));
-    PDL_HIP(hipMemcpyAsync(c->task_lg.p, c->h_task_lg_host.data(), (size_t) n_rows * 4, hipMemcpyHostToDevice, st));
-    if (!c->shard_set || S == G) {         // whole dataset: every gene has a task position (mirror mode needs the map)
+    if (c->dist) {            // genome -> rank, for the cell exchange
+        c->owner_of_genome.alloc((size_t) G * 4);
+        PDL_HIP(hipMemcpyAsync(c->owner_of_genome.p, c->h_owner.data(), (size_t) G * 4, hipMemcpyHostToDevice, st));
+    }
+    if (!c->shard_set || S == G || c->dist) {   // mirror mode: every gene's task position (0xffffffff: another GPU's row) and every genome's CM row
         c->h_taskpos_host.assign((size_t) N, 0xffffffffu);
         for (uint32_t q = 0; q < n_rows; q++) c->h_taskpos_host[c->h_task_rows_host[q]] = q;
         c->taskpos_of.alloc((size_t) N * 4);
         PDL_HIP(hipMemcpyAsync(c->taskpos_of.p, c->h_taskpos_host.data(), (size_t) N * 4, hipMemcpyHostToDevice, st));
+        c->local_genome.alloc((size_t) G * 4);      // (int32 -1 reads as 0xffffffff)
+        PDL_HIP(hipMemcpyAsync(c->local_genome.p, c->h_local_genome.data(), (size_t) G * 4, hipMemcpyHostToDevice, st));
     }
-    c->scratch2.alloc((size_t) (S + 1) * 8 + 64);      // task offsets | gathered cell offsets + 8 counters + cell total
-    PDL_HIP(hipMemcpyAsync(c->scratch2.p, c->h_task_row_off.data(), (size_t) (S + 1) * 4, hipMemcpyHostToDevice, st));
+    if (n_rows == 0) return;
+    c->task_rows.alloc((size_t) n_rows * 4); c->task_lg.alloc((size_t) n_rows * 4);
+    PDL_HIP(hipMemcpyAsync(c->task_rows.p, c->h_task_rows_host.data(), (size_t) n_rows * 4, hipMemcpyHostToDevice, st));
+    PDL_HIP(hipMemcpyAsync(c->task_lg.p, c->h_task_lg_host.data(), (size_t) n_rows * 4, hipMemcpyHostToDevice, st));
+    c->task_off.alloc((size_t) (S + 1) * 8 + 64);      // task offsets | gathered cell offsets + 8 counters + cell total
+    PDL_HIP(hipMemcpyAsync(c->task_off.p, c->h_task_row_off.data(), (size_t) (S + 1) * 4, hipMemcpyHostToDevice, st));
 }
 
 __global__ void k_iota_u32(uint32_t *dst, uint32_t n) { uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) dst[i] = i; }
 
-void pdl_run_score_all(pdl_ctx *c) {
-    hipStream_t st = c->stream;
+// ------------------------------------------------------------------------------------------------
+// The scoring pass on the host: plan (sizes, tiers), join (three tiers queued back to back), then the
+// emission-order pass.  Single GPU: join + order, the host looks at the counters once, at the end; a staging area
+// that turns out too small repeats the pass once with the size asked for (rows that did not fit hold no cell, so
+// everything queued behind an overflowing join stays inside its buffers).  Multi-GPU: join + outbox listing
+// (pdl_dist_score_begin), the caller's all-to-all, inbox filing + order (pdl_dist_score_finish).
+// ------------------------------------------------------------------------------------------------
+struct ScorePlan {
+    bool wide, mirror;
+    int tier1, occ_slot;
+    bool tiny_tier2;
+    uint32_t grid1, grid2, grid3;
+    unsigned long long slack;
+};
+
+static ScorePlan score_plan(pdl_ctx *c) {
     const uint32_t N = c->N, G = c->G;
+    const uint32_t n_rows = c->n_task_rows;
+    const uint32_t S = (uint32_t) c->shard.size();
+    ScorePlan pl{};
     // the LDS tiers pack the three sums of a cell in 21-bit fields; a gene with >= 2^20 k-mers could overflow them, so
     // such a dataset is scored entirely by the HBM kernel with 32-bit counters (the reference's ints)
-    const bool wide = c->max_kseq >= (1ull << 20);
+    pl.wide = c->max_kseq >= (1ull << 20);
     if (c->max_kseq >= (1ull << 31)) PDL_FAIL(PDL_ERR_UNSUPPORTED, "a gene with %llu k-mers exceeds the reference's int counters", (unsigned long long) c->max_kseq);
-    ev_begin(c, EV_SCORE_TOTAL);
-    if (!c->tasks_ready) pdl_prepare_tasks(c);
-    const uint32_t S = (uint32_t) c->shard.size();
-    const uint32_t n_rows = c->n_task_rows;
-    c->h_cell_off.assign(S + 1, 0);
-    c->Z = 0;
-    c->tm.emitted_cells = 0; c->tm.scored_rows = n_rows; c->tm.overflow_rows = 0; c->tm.join_launches = 0;
-    c->tm.scored_lookups = 0;
-    for (uint32_t i = 0; i < S; i++) c->tm.scored_lookups += c->h_genome_cost[c->shard[i]];
-    if (n_rows == 0) { c->scored = true; ev_end(c, EV_SCORE_TOTAL); return; }
-
-    // mirror mode (whole dataset on this device, ranges hold only the genes above the row): every staged cell
-    // (r, c) is also cell (c, r)
-    const bool mirror = c->upper_only;
-    if (mirror && (c->shard_set && S != G))
+    // mirror mode (ranges hold only the genes above the row): every staged cell (r, c) is also cell (c, r)
+    pl.mirror = c->upper_only;
+    if (pl.mirror && !c->dist && (c->shard_set && S != G))
         PDL_FAIL(PDL_ERR_STATE, "the dictionary was built for all genomes (upper-triangle ranges); a genome shard must be set before pdl_preprocess");
-
-    c->MS.alloc((size_t) n_rows * G * sizeof(float) + 16);      // (+16: cleared in whole 16-byte words)
-    c->CM.alloc((size_t) S * N * sizeof(float) + 16);
-    c->row_base.alloc((size_t) n_rows * 4); c->row_cnt.alloc((size_t) n_rows * 4); c->fin_off.alloc(((size_t) n_rows + 2) * 4);      // (+1: the scan stores its 64-bit total at [n_rows])
-    c->join_ctr.alloc(64);
-    c->row_desc.alloc((size_t) n_rows * sizeof(uint4));
-    c->row_desc2.alloc((size_t) n_rows * sizeof(uint4));
-    c->overflow_rows.alloc((size_t) n_rows * 4 * 2);     // list A (tier 1 -> 2) and list B (tier 2 -> 3)
-    if (mirror) c->mirror_cnt.alloc((size_t) n_rows * 4 * 3 + 16);    // counts | offsets | cursors
-    hipLaunchKernelGGL(k_row_desc, dim3((n_rows + 255) / 256), dim3(256), 0, st, c->task_rows.as<uint32_t>(), c->seq_off.as<uint32_t>(),
-                       n_rows, c->row_desc.as<uint4>());
-
     int cus = c->cus;
     if (cus <= 0) {
         cus = 256;
@@ -976,186 +1065,254 @@ void pdl_run_score_all(pdl_ctx *c) {
         if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) cus = prop.multiProcessorCount;
         c->cus = cus;
     }
-
     // ---- tiers ---------------------------------------------------------------------------------------
     //   1  k_join_lds<FILTER>     small table + "seen twice" bitmap, several rows resident per CU
     //   2  k_join_lds<13,1024>    128-KiB table holding every column a row touches, one row per CU
     //   3  k_join_hbm             direct-addressed tables in HBM
-    // A tier hands the rows it cannot hold to the next one through a device-side list; the launches of the three
-    // tiers, the emission-order pass and the per-genome offsets are queued back to back and the host looks at the
-    // counters once, at the end (a staging area that turns out too small repeats the pass).
-    // PDL_JOIN_TIER1 = 0 | 9 | 10 | 11 picks the tier-1 table (0: skip tier 1); PDL_JOIN_TABLE_BITS=9 swaps
-    // tier 2 for a tiny table so that tests can reach tier 3 with small inputs.
-    int tier1 = G <= 320 ? 10 : 11;     // keys per row ~ homologs (about one per genome) + repeated/colliding noise
-    if (const char *e = getenv("PDL_JOIN_TIER1")) { const int v = atoi(e); if (v == 0 || (v >= 9 && v <= 11) || v == 20 || v == 21) tier1 = v; }
-    bool tiny_tier2 = false;
-    if (const char *e = getenv("PDL_JOIN_TABLE_BITS")) tiny_tier2 = atoi(e) == 9;
+    // A tier hands the rows it cannot hold to the next one through a device-side list.  pdl_set_option "join_tier1"
+    // picks the tier-1 table (0: skip tier 1; 20 / 21: 1024 / 2048-slot tables WITHOUT the filter, one pass);
+    // "join_tiny_tier2" swaps tier 2 for a tiny table so that tests can reach tier 3 with small inputs.
+    pl.tier1 = c->opt_tier1 >= 0 ? c->opt_tier1 : (G <= 320 ? 10 : 11);    // keys per row ~ homologs (about one per genome) + repeated/colliding noise
+    pl.tiny_tier2 = c->opt_tiny_tier2;
     auto occupancy = [&](const void *fn, int threads) {
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, threads, 0) != hipSuccess || nb < 1) nb = 1;
         return (uint32_t) nb;
     };
-    // (20 / 21: 1024 / 2048-slot tables WITHOUT the filter, one pass)
+    const int tier1 = pl.tier1;
     const void *fn1 = tier1 == 9 ? (const void *) k_join_lds<9, 128, true>
                     : tier1 == 10 ? (const void *) k_join_lds<10, 256, true>
                     : tier1 == 11 ? (const void *) k_join_lds<11, 256, true>
                     : tier1 == 20 ? (const void *) k_join_lds<10, 256, false> : (const void *) k_join_lds<11, 256, false>;
     const int t1_threads = tier1 == 9 ? 128 : 256;
-    const int occ_slot = tier1 >= 20 ? tier1 - 20 + 3 : tier1 - 9;
-    if (tier1 && c->occ_tier1[occ_slot] == 0) c->occ_tier1[occ_slot] = occupancy(fn1, t1_threads);
-    const uint32_t grid1 = tier1 ? std::min<uint32_t>(n_rows, (uint32_t) cus * c->occ_tier1[occ_slot]) : 0;
-    const uint32_t grid2 = std::min<uint32_t>(n_rows, (uint32_t) cus * (tiny_tier2 ? 4 : 1));
-    const uint32_t grid3 = (uint32_t) std::min<int>(cus, 64);
-    const size_t hbm_bytes = (size_t) grid3 * N * ((wide ? 2 : 1) * sizeof(uint64_t) + 3 * sizeof(uint32_t));
+    pl.occ_slot = tier1 >= 20 ? tier1 - 20 + 3 : (tier1 ? tier1 - 9 : 0);
+    if (tier1 && c->occ_tier1[pl.occ_slot] == 0) c->occ_tier1[pl.occ_slot] = occupancy(fn1, t1_threads);
+    pl.grid1 = tier1 ? std::min<uint32_t>(n_rows, (uint32_t) cus * c->occ_tier1[pl.occ_slot]) : 0;
+    pl.grid2 = std::min<uint32_t>(n_rows, (uint32_t) cus * (pl.tiny_tier2 ? 4 : 1));
+    pl.grid3 = (uint32_t) std::min<int>(cus, 64);
+    const size_t hbm_bytes = (size_t) pl.grid3 * N * ((pl.wide ? 2 : 1) * sizeof(uint64_t) + 3 * sizeof(uint32_t));
     if (c->glb_table.bytes < hbm_bytes) { c->glb_table.alloc(hbm_bytes); c->glb_clean = false; }
     if (!c->glb_clean) {      // k_join_hbm leaves its tables zeroed: one memset per allocation
-        PDL_HIP(hipMemsetAsync(c->glb_table.p, 0, hbm_bytes, st));
+        PDL_HIP(hipMemsetAsync(c->glb_table.p, 0, hbm_bytes, c->stream));
         c->glb_clean = true;
     }
+    // Every workgroup reserves staging in chunks of CELL_CHUNK cells: a partly used chunk per workgroup of every tier
+    pl.slack = 2ull * (pl.grid1 + pl.grid2 + pl.grid3) * CELL_CHUNK;
+    return pl;
+}
 
-    // staging capacity: emitted cells are, in practice, the homologous pairs (about one per genome and row);
-    // if the guess is short the pass is repeated once with the exact size.  Every workgroup reserves staging in
-    // chunks of CELL_CHUNK cells: allow a partly used chunk per workgroup of every tier on top of the estimate.
-    const unsigned long long slack = 2ull * (grid1 + grid2 + grid3) * CELL_CHUNK;
-    unsigned long long cap = std::max<unsigned long long>(1ull << 20, (unsigned long long) n_rows * (G + 16ull));
-    cap = std::min<unsigned long long>(cap, std::max<unsigned long long>(c->P, 1ull)) + slack;
+// buffers that depend on the row count only
+static void score_alloc_rows(pdl_ctx *c, const ScorePlan &pl) {
+    const uint32_t N = c->N, G = c->G, n_rows = c->n_task_rows;
+    const uint32_t S = (uint32_t) c->shard.size();
+    c->MS.alloc((size_t) n_rows * G * sizeof(float) + 16);      // (+16: cleared in whole 16-byte words)
+    c->CM.alloc((size_t) S * N * sizeof(float) + 16);
+    c->row_base.alloc((size_t) n_rows * 4); c->row_cnt.alloc((size_t) n_rows * 4); c->fin_off.alloc(((size_t) n_rows + 2) * 4);      // (+1: the scan stores its 64-bit total at [n_rows])
+    c->join_ctr.alloc(64);
+    c->row_desc.alloc((size_t) n_rows * sizeof(uint4));
+    c->row_desc2.alloc((size_t) n_rows * sizeof(uint4));
+    c->overflow_rows.alloc((size_t) n_rows * 4 * 2);     // list A (tier 1 -> 2) and list B (tier 2 -> 3)
+    if (pl.mirror) c->mirror_cnt.alloc((size_t) n_rows * 4 * 3 + 16);    // counts | offsets | cursors
+    hipLaunchKernelGGL(k_row_desc, dim3((n_rows + 255) / 256), dim3(256), 0, c->stream, c->task_rows.as<uint32_t>(), c->seq_off.as<uint32_t>(),
+                       n_rows, c->row_desc.as<uint4>());
+}
+
+// staging for `cap` cells of this context's rows + `extra` cells received from other GPUs (slots cap .. cap + extra)
+static void score_alloc_cells(pdl_ctx *c, const ScorePlan &pl, unsigned long long cap, unsigned long long extra, bool keep) {
+    const unsigned long long st_total = cap + extra;
+    const unsigned long long fcap = pl.mirror ? 2 * cap + extra : cap;          // final cells: staged ones + their mirrors + received ones
+    if (fcap >= 0xffffffffull) PDL_FAIL(PDL_ERR_UNSUPPORTED, "more than 2^32 emitted cells on one device: shard the genomes over more devices");
+    DevBuf *st[6] = {&c->st_score, &c->st_perc, &c->st_tr, &c->st_col, &c->st_first, &c->st_src};
+    for (int i = 0; i < (pl.mirror ? 6 : 5); i++) { if (keep) st[i]->grow_keep(st_total * 4, c->stream); else st[i]->alloc(st_total * 4); }
+    c->c_score.alloc(fcap * 4); c->c_perc.alloc(fcap * 4); c->c_tr.alloc(fcap * 4); c->c_row.alloc(fcap * 4); c->c_col.alloc(fcap * 4);
+    if (pl.mirror) c->mirror_ref.alloc(st_total * 4);
+    c->st_cap = cap;
+}
+
+static JoinArgs join_args(pdl_ctx *c, const ScorePlan &pl) {
+    JoinArgs a{};
+    a.post = pdl_postings(c); a.ranges = c->ranges.as<uint4>(); a.seq_off = c->seq_off.as<uint32_t>();
+    a.kseq_len = c->kseq_len.as<uint32_t>(); a.genome_of = c->d_gen;
+    a.task_rows = c->task_rows.as<uint32_t>(); a.task_lg = c->task_lg.as<uint32_t>();
+    a.N = c->N; a.G = c->G; a.k = c->rp.k;
+    a.min_kseq = (uint32_t) std::max<uint64_t>(c->min_kseq, 1); a.canonical = (c->flags & PDL_FLAG_CANONICAL_ORDER) ? 1u : 0u;
+    a.MS = c->MS.as<float>(); a.CM = c->CM.as<float>();
+    a.row_base = c->row_base.as<uint32_t>(); a.row_cnt = c->row_cnt.as<uint32_t>();
+    a.st_score = c->st_score.as<float>(); a.st_perc = c->st_perc.as<float>(); a.st_tr = c->st_tr.as<float>();
+    a.st_col = c->st_col.as<uint32_t>(); a.st_first = c->st_first.as<uint32_t>(); a.st_cap = c->st_cap;
+    a.mirror = pl.mirror ? 1u : 0u;
+    if (pl.mirror) {
+        a.st_src = c->st_src.as<uint32_t>(); a.taskpos_of = c->taskpos_of.as<uint32_t>(); a.local_genome = c->local_genome.as<uint32_t>();
+        a.mirror_cnt = c->mirror_cnt.as<uint32_t>();
+    }
+    return a;
+}
+
+// clears the maxima, the counters and the mirror bookkeeping, then queues the three tiers
+static void score_join(pdl_ctx *c, const ScorePlan &pl) {
+    hipStream_t st = c->stream;
+    const uint32_t N = c->N, G = c->G, n_rows = c->n_task_rows;
+    const uint32_t S = (uint32_t) c->shard.size();
+    const int tier1 = pl.tier1;
+    {   // maxima, counters and (mirror mode) the per-row mirror counts/offsets/cursors start at zero: one launch
+        auto n16 = [](size_t bytes) { return (unsigned long long) ((bytes + 15) / 16); };      // (buffers are sized in whole 16-byte words)
+        ZeroRanges z{};
+        z.p[0] = c->MS.as<uint4>(); z.n16[0] = n16((size_t) n_rows * G * sizeof(float));
+        z.p[1] = c->CM.as<uint4>(); z.n16[1] = n16((size_t) S * N * sizeof(float));
+        z.p[2] = c->join_ctr.as<uint4>(); z.n16[2] = n16(64);
+        z.p[3] = pl.mirror ? c->mirror_cnt.as<uint4>() : nullptr; z.n16[3] = pl.mirror ? n16((size_t) n_rows * 4 * 3) : 0;
+        const unsigned long long most = std::max(z.n16[0], z.n16[1]);
+        hipLaunchKernelGGL(k_zero_ranges, dim3((uint32_t) std::min<unsigned long long>((most + 255) / 256 + 1, (unsigned long long) c->cus * 16)), dim3(256), 0, st, z);
+    }
+    JoinArgs a = join_args(c, pl);
+    // counters: 0 cursor tier 1 | 1 rows for tier 2 | 2 cursor tier 2 | 3 rows for tier 3 | 4-5 cell cursor | 6 errors | 7 cursor tier 3 | 9 wide rows seen by K-order
+    uint32_t *ctr32 = c->join_ctr.as<uint32_t>();
+    uint32_t *list_a = c->overflow_rows.as<uint32_t>(), *list_b = list_a + n_rows;
+    a.error_count = ctr32 + 6;
+    a.cell_cursor = reinterpret_cast<unsigned long long *>(ctr32 + 4);
+
+    ev_begin(c, EV_JOIN);
+    if (pl.wide) {          // every row straight to tier 3: list B = all task positions
+        hipLaunchKernelGGL(k_iota_u32, dim3((n_rows + 255) / 256), dim3(256), 0, st, list_b, n_rows);
+        PDL_HIP(hipMemcpyAsync(ctr32 + 3, &c->n_task_rows, 4, hipMemcpyHostToDevice, st));
+    }
+    // tier 1
+    a.work = nullptr; a.desc = c->row_desc.as<uint4>(); a.n_work = pl.wide ? 0 : n_rows; a.n_work_ptr = nullptr;
+    a.work_cursor = ctr32 + 0; a.overflow_count = ctr32 + 1; a.overflow_rows = list_a;
+    a.work_batch = std::max<uint32_t>(1, std::min<uint32_t>(8, n_rows / (std::max<uint32_t>(pl.grid1, 1) * 8)));
+    if (tier1 == 9) hipLaunchKernelGGL((k_join_lds<9, 128, true>), dim3(pl.grid1), dim3(128), 0, st, a);
+    else if (tier1 == 10) hipLaunchKernelGGL((k_join_lds<10, 256, true>), dim3(pl.grid1), dim3(256), 0, st, a);
+    else if (tier1 == 11) hipLaunchKernelGGL((k_join_lds<11, 256, true>), dim3(pl.grid1), dim3(256), 0, st, a);
+    else if (tier1 == 20) hipLaunchKernelGGL((k_join_lds<10, 256, false>), dim3(pl.grid1), dim3(256), 0, st, a);
+    else if (tier1 == 21) hipLaunchKernelGGL((k_join_lds<11, 256, false>), dim3(pl.grid1), dim3(256), 0, st, a);
+    // tier 2 over list A (or over everything when tier 1 is off)
+    if (tier1) {
+        hipLaunchKernelGGL(k_row_desc_list, dim3((n_rows + 255) / 256), dim3(256), 0, st, list_a, ctr32 + 1, c->task_rows.as<uint32_t>(),
+                           c->seq_off.as<uint32_t>(), c->row_desc2.as<uint4>());
+        a.desc = c->row_desc2.as<uint4>(); a.n_work = 0; a.n_work_ptr = ctr32 + 1;
+    }
+    a.work_cursor = ctr32 + 2; a.overflow_count = ctr32 + 3; a.overflow_rows = list_b;
+    a.work_batch = tier1 ? 1 : std::max<uint32_t>(1, std::min<uint32_t>(8, n_rows / (pl.grid2 * 8)));
+    if (pl.wide && !tier1) a.n_work = 0;
+    if (pl.tiny_tier2) hipLaunchKernelGGL((k_join_lds<9, 64, false>), dim3(pl.grid2), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((k_join_lds<13, 1024, false>), dim3(pl.grid2), dim3(1024), 0, st, a);
+    PDL_HIP(hipGetLastError());
+    ev_end(c, EV_JOIN);
+    // tier 3 over list B
+    a.hbm_acc = c->glb_table.as<unsigned long long>();
+    a.hbm_u32 = reinterpret_cast<uint32_t *>(a.hbm_acc + (size_t) pl.grid3 * N * (pl.wide ? 2 : 1));
+    a.work = list_b; a.n_work = 0; a.n_work_ptr = ctr32 + 3; a.work_cursor = ctr32 + 7; a.work_batch = 1;
+    ev_begin(c, EV_JOIN_OVF);
+    c->glb_clean = false;
+    if (pl.wide) hipLaunchKernelGGL(k_join_hbm<true>, dim3(pl.grid3), dim3(HBM_THREADS), 0, st, a);
+    else hipLaunchKernelGGL(k_join_hbm<false>, dim3(pl.grid3), dim3(HBM_THREADS), 0, st, a);
+    PDL_HIP(hipGetLastError());
+    ev_end(c, EV_JOIN_OVF);
+    c->tm.join_launches += 3;
+}
+
+// K-order over the staged cells (+ the n_inbox cells filed at slots st_cap ..), then the one look at the counters.
+// Returns the staging cells the join asked for (> st_cap: the pass must be repeated).
+static unsigned long long score_order(pdl_ctx *c, const ScorePlan &pl, uint32_t n_inbox, int ev_total) {
+    hipStream_t st = c->stream;
+    const uint32_t n_rows = c->n_task_rows;
+    const uint32_t S = (uint32_t) c->shard.size();
     uint64_t *d_scal = c->scalars.as<uint64_t>();
+    uint32_t *ctr32 = c->join_ctr.as<uint32_t>();
+    ev_begin(c, EV_ORDER);
+    const uint32_t *d_mcnt = pl.mirror ? c->mirror_cnt.as<uint32_t>() : nullptr;
+    // the scan's total (all emitted cells, < 2^32) also closes fin_off: the low word of the u64 lands in fin_off[n_rows]
+    scan_and_apply(c, n_rows, RowCntFlag{c->row_cnt.as<uint32_t>(), d_mcnt}, FinOffApply{c->fin_off.as<uint32_t>()}, d_scal + 6,
+                   reinterpret_cast<uint64_t *>(c->fin_off.as<uint32_t>() + n_rows));
+    OrderArgs o{};
+    if (pl.mirror) {
+        uint32_t *m_off = c->mirror_cnt.as<uint32_t>() + n_rows, *m_cur = m_off + n_rows;
+        scan_and_apply(c, n_rows, MirrorCntFlag{d_mcnt}, FinOffApply{m_off}, d_scal + 9);
+        hipLaunchKernelGGL(k_mirror_refs, dim3((n_rows + 3) / 4), dim3(256), 0, st, c->row_base.as<uint32_t>(), c->row_cnt.as<uint32_t>(),
+                           c->st_col.as<uint32_t>(), c->taskpos_of.as<uint32_t>(), m_off, m_cur, n_rows, c->mirror_ref.as<uint32_t>());
+        if (n_inbox)
+            hipLaunchKernelGGL(k_mirror_refs_inbox, dim3((n_inbox + 255) / 256), dim3(256), 0, st, c->st_col.as<uint32_t>(), c->taskpos_of.as<uint32_t>(),
+                               m_off, m_cur, (uint32_t) c->st_cap, n_inbox, c->mirror_ref.as<uint32_t>());
+        o.st_src = c->st_src.as<uint32_t>(); o.mirror_cnt = d_mcnt; o.mirror_off = m_off; o.mirror_ref = c->mirror_ref.as<uint32_t>();
+    }
+    o.row_base = c->row_base.as<uint32_t>(); o.row_cnt = c->row_cnt.as<uint32_t>(); o.fin_off = c->fin_off.as<uint32_t>();
+    o.task_rows = c->task_rows.as<uint32_t>();
+    o.st_score = c->st_score.as<float>(); o.st_perc = c->st_perc.as<float>(); o.st_tr = c->st_tr.as<float>();
+    o.st_col = c->st_col.as<uint32_t>(); o.st_first = c->st_first.as<uint32_t>();
+    o.c_score = c->c_score.as<float>(); o.c_perc = c->c_perc.as<float>(); o.c_tr = c->c_tr.as<float>();
+    o.c_row = c->c_row.as<int32_t>(); o.c_col = c->c_col.as<int32_t>();
+    o.n_rows = n_rows; o.canonical = (c->flags & PDL_FLAG_CANONICAL_ORDER) ? 1u : 0u;
+    o.wide_rows = ctr32 + 9;                 // (counter block, zero since the clearing launch)
+    hipLaunchKernelGGL(k_order_rows_wave, dim3((n_rows + 3) / 4), dim3(256), 0, st, o);
+    hipLaunchKernelGGL(k_order_rows, dim3(std::min<uint32_t>(n_rows, (uint32_t) c->cus * 8)), dim3(ORDER_THREADS), 0, st, o);   // rows of more than 256 cells, if any
+    PDL_HIP(hipGetLastError());
+    ev_end(c, EV_ORDER);
+
+    // first cell of every shard genome = fin_off at its first task row; then the one look at the counters
+    uint32_t *d_idx = c->task_off.as<uint32_t>();
+    uint32_t *d_out = d_idx + (S + 1);
+    hipLaunchKernelGGL(k_gather_u32, dim3((S + 1 + 10 + 255) / 256), dim3(256), 0, st, c->fin_off.as<uint32_t>(), d_idx, S + 1, d_out,
+                       c->join_ctr.as<uint32_t>(), reinterpret_cast<const uint32_t *>(d_scal + 6));
+    c->h_fin.resize(S + 1);
+    uint32_t h_ctr[8];
+    uint64_t zsum = 0;
+    {
+        PinRead rd(c);
+        const uint32_t *pf = rd.add<uint32_t>(d_out, S + 1 + 10);
+        ev_end(c, ev_total);
+        rd.sync();
+        memcpy(c->h_fin.data(), pf, (size_t) (S + 1) * 4);
+        memcpy(h_ctr, pf + S + 1, sizeof(h_ctr));
+        memcpy(&zsum, pf + S + 1 + 8, sizeof(zsum));
+    }
+    c->glb_clean = true;
+    c->tm.overflow_rows = h_ctr[3];
+    c->tm.tier2_rows = pl.tier1 ? h_ctr[1] : n_rows;
+    if (h_ctr[6]) PDL_FAIL(PDL_ERR_DEVICE, "join: %u internal consistency violations", h_ctr[6]);
+    unsigned long long z;                    // staging cells reserved (>= cells staged: chunk tails are unused)
+    memcpy(&z, &h_ctr[4], sizeof(z));
+    if (z <= c->st_cap) {
+        c->Z = zsum;
+        c->tm.emitted_cells = c->Z;
+        for (uint32_t i = 0; i <= S; i++) c->h_cell_off[i] = c->h_fin[i];
+    }
+    return z;
+}
+
+static unsigned long long first_staging_cap(pdl_ctx *c, const ScorePlan &pl, uint64_t lookups) {
+    // staging capacity: emitted cells are, in practice, the homologous pairs (about one per genome and row);
+    // if the guess is short the pass is repeated once with the exact size ("staging_cap" forces that in tests)
+    if (c->opt_staging_cap) return c->opt_staging_cap;
+    unsigned long long cap = std::max<unsigned long long>(1ull << 20, (unsigned long long) c->n_task_rows * (c->G + 16ull));
+    return std::min<unsigned long long>(cap, std::max<unsigned long long>(lookups, 1ull)) + pl.slack;
+}
+
+static void score_reset(pdl_ctx *c) {
+    const uint32_t S = (uint32_t) c->shard.size();
+    c->h_cell_off.assign(S + 1, 0);
+    c->Z = 0;
+    c->tm.emitted_cells = 0; c->tm.scored_rows = c->n_task_rows; c->tm.overflow_rows = 0; c->tm.join_launches = 0;
+    c->tm.scored_lookups = 0; c->tm.walked_lookups = 0; c->tm.outbox_cells = c->tm.inbox_cells = 0;
+    c->tm.dist_score_begin_ms = c->tm.dist_score_finish_ms = 0.f;
+    for (uint32_t i = 0; i < S; i++) c->tm.scored_lookups += c->h_genome_cost[c->shard[i]];
+}
+
+void pdl_run_score_all(pdl_ctx *c) {
+    ev_begin(c, EV_SCORE_TOTAL);
+    if (!c->tasks_ready) pdl_prepare_tasks(c);
+    score_reset(c);
+    if (c->n_task_rows == 0) { c->scored = true; ev_end(c, EV_SCORE_TOTAL); return; }
+    const ScorePlan pl = score_plan(c);
+    c->tm.walked_lookups = pl.mirror ? (c->P - c->Ushared) / 2 : c->tm.scored_lookups;       // sum s(s-1)/2 = (sum s^2 - sum s) / 2
+    score_alloc_rows(c, pl);
+    unsigned long long cap = first_staging_cap(c, pl, c->P);
     for (int attempt = 0; attempt < 2; attempt++) {
-        const unsigned long long fcap = mirror ? 2 * cap : cap;          // final cells: staged ones + their mirrors
-        if (fcap >= 0xffffffffull) PDL_FAIL(PDL_ERR_UNSUPPORTED, "more than 2^32 emitted cells on one device: shard the genomes over more devices");
-        c->st_cap = cap;
-        c->st_score.alloc(cap * 4); c->st_perc.alloc(cap * 4); c->st_tr.alloc(cap * 4); c->st_col.alloc(cap * 4); c->st_first.alloc(cap * 4);
-        c->c_score.alloc(fcap * 4); c->c_perc.alloc(fcap * 4); c->c_tr.alloc(fcap * 4); c->c_row.alloc(fcap * 4); c->c_col.alloc(fcap * 4);
-        if (mirror) {
-            c->st_src.alloc(cap * 4);
-            c->mirror_ref.alloc(cap * 4);
-        }
-        {   // maxima, counters and (mirror mode) the per-row mirror counts/offsets/cursors start at zero: one launch
-            auto n16 = [](size_t bytes) { return (unsigned long long) ((bytes + 15) / 16); };      // (buffers are sized in whole 16-byte words)
-            ZeroRanges z{};
-            z.p[0] = c->MS.as<uint4>(); z.n16[0] = n16((size_t) n_rows * G * sizeof(float));
-            z.p[1] = c->CM.as<uint4>(); z.n16[1] = n16((size_t) S * N * sizeof(float));
-            z.p[2] = c->join_ctr.as<uint4>(); z.n16[2] = n16(64);
-            z.p[3] = mirror ? c->mirror_cnt.as<uint4>() : nullptr; z.n16[3] = mirror ? n16((size_t) n_rows * 4 * 3) : 0;
-            const unsigned long long most = std::max(z.n16[0], z.n16[1]);
-            hipLaunchKernelGGL(k_zero_ranges, dim3((uint32_t) std::min<unsigned long long>((most + 255) / 256 + 1, (unsigned long long) cus * 16)), dim3(256), 0, st, z);
-        }
-
-        JoinArgs a{};
-        a.post = c->post.as<uint2>(); a.ranges = c->ranges.as<uint4>(); a.seq_off = c->seq_off.as<uint32_t>();
-        a.kseq_len = c->kseq_len.as<uint32_t>(); a.genome_of = c->d_gen;
-        a.task_rows = c->task_rows.as<uint32_t>(); a.task_lg = c->task_lg.as<uint32_t>();
-        a.N = N; a.G = G; a.k = c->rp.k;
-        a.min_kseq = (uint32_t) std::max<uint64_t>(c->min_kseq, 1); a.canonical = (c->flags & PDL_FLAG_CANONICAL_ORDER) ? 1u : 0u;
-        a.MS = c->MS.as<float>(); a.CM = c->CM.as<float>();
-        a.row_base = c->row_base.as<uint32_t>(); a.row_cnt = c->row_cnt.as<uint32_t>();
-        a.st_score = c->st_score.as<float>(); a.st_perc = c->st_perc.as<float>(); a.st_tr = c->st_tr.as<float>();
-        a.st_col = c->st_col.as<uint32_t>(); a.st_first = c->st_first.as<uint32_t>(); a.st_cap = cap;
-        a.mirror = mirror ? 1u : 0u;
-        if (mirror) { a.st_src = c->st_src.as<uint32_t>(); a.taskpos_of = c->taskpos_of.as<uint32_t>(); a.mirror_cnt = c->mirror_cnt.as<uint32_t>(); }
-        // counters: 0 cursor tier 1 | 1 rows for tier 2 | 2 cursor tier 2 | 3 rows for tier 3 | 4-5 cell cursor | 6 errors | 7 cursor tier 3
-        uint32_t *ctr32 = c->join_ctr.as<uint32_t>();
-        uint32_t *list_a = c->overflow_rows.as<uint32_t>(), *list_b = list_a + n_rows;
-        a.error_count = ctr32 + 6;
-        a.cell_cursor = reinterpret_cast<unsigned long long *>(ctr32 + 4);
-
-        ev_begin(c, EV_JOIN);
-        if (wide) {          // every row straight to tier 3: list B = all task positions
-            hipLaunchKernelGGL(k_iota_u32, dim3((n_rows + 255) / 256), dim3(256), 0, st, list_b, n_rows);
-            PDL_HIP(hipMemcpyAsync(ctr32 + 3, &c->n_task_rows, 4, hipMemcpyHostToDevice, st));
-        }
-        // tier 1
-        a.work = nullptr; a.desc = c->row_desc.as<uint4>(); a.n_work = wide ? 0 : n_rows; a.n_work_ptr = nullptr;
-        a.work_cursor = ctr32 + 0; a.overflow_count = ctr32 + 1; a.overflow_rows = list_a;
-        a.work_batch = std::max<uint32_t>(1, std::min<uint32_t>(8, n_rows / (std::max<uint32_t>(grid1, 1) * 8)));
-        if (tier1 == 9) hipLaunchKernelGGL((k_join_lds<9, 128, true>), dim3(grid1), dim3(128), 0, st, a);
-        else if (tier1 == 10) hipLaunchKernelGGL((k_join_lds<10, 256, true>), dim3(grid1), dim3(256), 0, st, a);
-        else if (tier1 == 11) hipLaunchKernelGGL((k_join_lds<11, 256, true>), dim3(grid1), dim3(256), 0, st, a);
-        else if (tier1 == 20) hipLaunchKernelGGL((k_join_lds<10, 256, false>), dim3(grid1), dim3(256), 0, st, a);
-        else if (tier1 == 21) hipLaunchKernelGGL((k_join_lds<11, 256, false>), dim3(grid1), dim3(256), 0, st, a);
-        // tier 2 over list A (or over everything when tier 1 is off)
-        if (tier1) {
-            hipLaunchKernelGGL(k_row_desc_list, dim3((n_rows + 255) / 256), dim3(256), 0, st, list_a, ctr32 + 1, c->task_rows.as<uint32_t>(),
-                               c->seq_off.as<uint32_t>(), c->row_desc2.as<uint4>());
-            a.desc = c->row_desc2.as<uint4>(); a.n_work = 0; a.n_work_ptr = ctr32 + 1;
-        }
-        a.work_cursor = ctr32 + 2; a.overflow_count = ctr32 + 3; a.overflow_rows = list_b;
-        a.work_batch = tier1 ? 1 : std::max<uint32_t>(1, std::min<uint32_t>(8, n_rows / (grid2 * 8)));
-        if (wide && !tier1) a.n_work = 0;
-        if (tiny_tier2) hipLaunchKernelGGL((k_join_lds<9, 64, false>), dim3(grid2), dim3(64), 0, st, a);
-        else hipLaunchKernelGGL((k_join_lds<13, 1024, false>), dim3(grid2), dim3(1024), 0, st, a);
-        PDL_HIP(hipGetLastError());
-        ev_end(c, EV_JOIN);
-        // tier 3 over list B
-        a.hbm_acc = c->glb_table.as<unsigned long long>();
-        a.hbm_u32 = reinterpret_cast<uint32_t *>(a.hbm_acc + (size_t) grid3 * N * (wide ? 2 : 1));
-        a.work = list_b; a.n_work = 0; a.n_work_ptr = ctr32 + 3; a.work_cursor = ctr32 + 7; a.work_batch = 1;
-        ev_begin(c, EV_JOIN_OVF);
-        c->glb_clean = false;
-        if (wide) hipLaunchKernelGGL(k_join_hbm<true>, dim3(grid3), dim3(HBM_THREADS), 0, st, a);
-        else hipLaunchKernelGGL(k_join_hbm<false>, dim3(grid3), dim3(HBM_THREADS), 0, st, a);
-        PDL_HIP(hipGetLastError());
-        ev_end(c, EV_JOIN_OVF);
-        c->tm.join_launches += 3;
-
-        // ---- order ----------------------------------------------------------------------------------
-        ev_begin(c, EV_ORDER);
-        const uint32_t *d_mcnt = mirror ? c->mirror_cnt.as<uint32_t>() : nullptr;
-        // the scan's total (all emitted cells, < 2^32) also closes fin_off: the low word of the u64 lands in fin_off[n_rows]
-        scan_and_apply(c, n_rows, RowCntFlag{c->row_cnt.as<uint32_t>(), d_mcnt}, FinOffApply{c->fin_off.as<uint32_t>()}, d_scal + 6,
-                       reinterpret_cast<uint64_t *>(c->fin_off.as<uint32_t>() + n_rows));
-        OrderArgs o{};
-        if (mirror) {
-            uint32_t *m_off = c->mirror_cnt.as<uint32_t>() + n_rows, *m_cur = m_off + n_rows;
-            scan_and_apply(c, n_rows, MirrorCntFlag{d_mcnt}, FinOffApply{m_off}, d_scal + 9);
-            hipLaunchKernelGGL(k_mirror_refs, dim3((n_rows + 3) / 4), dim3(256), 0, st, c->row_base.as<uint32_t>(), c->row_cnt.as<uint32_t>(),
-                               c->st_col.as<uint32_t>(), c->taskpos_of.as<uint32_t>(), m_off, m_cur, n_rows, c->mirror_ref.as<uint32_t>());
-            o.st_src = c->st_src.as<uint32_t>(); o.mirror_cnt = d_mcnt; o.mirror_off = m_off; o.mirror_ref = c->mirror_ref.as<uint32_t>();
-        }
-        o.row_base = c->row_base.as<uint32_t>(); o.row_cnt = c->row_cnt.as<uint32_t>(); o.fin_off = c->fin_off.as<uint32_t>();
-        o.task_rows = c->task_rows.as<uint32_t>();
-        o.st_score = c->st_score.as<float>(); o.st_perc = c->st_perc.as<float>(); o.st_tr = c->st_tr.as<float>();
-        o.st_col = c->st_col.as<uint32_t>(); o.st_first = c->st_first.as<uint32_t>();
-        o.c_score = c->c_score.as<float>(); o.c_perc = c->c_perc.as<float>(); o.c_tr = c->c_tr.as<float>();
-        o.c_row = c->c_row.as<int32_t>(); o.c_col = c->c_col.as<int32_t>();
-        o.n_rows = n_rows; o.canonical = (c->flags & PDL_FLAG_CANONICAL_ORDER) ? 1u : 0u;
-        o.wide_rows = ctr32 + 9;                 // (counter block, zero since the clearing launch)
-        hipLaunchKernelGGL(k_order_rows_wave, dim3((n_rows + 3) / 4), dim3(256), 0, st, o);
-        hipLaunchKernelGGL(k_order_rows, dim3(std::min<uint32_t>(n_rows, (uint32_t) cus * 8)), dim3(ORDER_THREADS), 0, st, o);   // rows of more than 256 cells, if any
-        PDL_HIP(hipGetLastError());
-        ev_end(c, EV_ORDER);
-
-        // first cell of every shard genome = fin_off at its first task row; then the one look at the counters
-        uint32_t *d_idx = c->scratch2.as<uint32_t>();
-        uint32_t *d_out = d_idx + (S + 1);
-        hipLaunchKernelGGL(k_gather_u32, dim3((S + 1 + 10 + 255) / 256), dim3(256), 0, st, c->fin_off.as<uint32_t>(), d_idx, S + 1, d_out,
-                           c->join_ctr.as<uint32_t>(), reinterpret_cast<const uint32_t *>(d_scal + 6));
-        c->h_fin.resize(S + 1);
-        uint32_t h_ctr[8];
-        uint64_t zsum = 0;
-        {
-            PinRead rd(c);
-            const uint32_t *pf = rd.add<uint32_t>(d_out, S + 1 + 10);
-            ev_end(c, EV_SCORE_TOTAL);
-            rd.sync();
-            memcpy(c->h_fin.data(), pf, (size_t) (S + 1) * 4);
-            memcpy(h_ctr, pf + S + 1, sizeof(h_ctr));
-            memcpy(&zsum, pf + S + 1 + 8, sizeof(zsum));
-        }
-        c->glb_clean = true;
-        c->tm.overflow_rows = h_ctr[3];
-        c->tm.tier2_rows = tier1 ? h_ctr[1] : n_rows;
-        if (h_ctr[6]) PDL_FAIL(PDL_ERR_DEVICE, "join: %u internal consistency violations", h_ctr[6]);
-        unsigned long long z;                    // staging cells reserved (>= cells staged: chunk tails are unused)
-        memcpy(&z, &h_ctr[4], sizeof(z));
-        if (z <= cap) {
-            c->Z = zsum;
-            c->tm.emitted_cells = c->Z;
-            for (uint32_t i = 0; i <= S; i++) c->h_cell_off[i] = c->h_fin[i];
-            break;
-        }
+        score_alloc_cells(c, pl, cap, 0, false);
+        score_join(c, pl);
+        const unsigned long long z = score_order(c, pl, 0, EV_SCORE_TOTAL);
+        if (z <= cap) break;
         if (attempt == 1) PDL_FAIL(PDL_ERR_DEVICE, "staging overflow persisted (%llu cells > %llu)", z, cap);
-        cap = z + slack;      // what was asked for plus chunk slack, second and last attempt
+        cap = z + pl.slack;      // what was asked for plus chunk slack, second and last attempt
         ev_begin(c, EV_SCORE_TOTAL);
     }
     c->tm.join_ms = ev_ms(c, EV_JOIN);
@@ -1163,4 +1320,114 @@ void pdl_run_score_all(pdl_ctx *c) {
     c->tm.order_ms = ev_ms(c, EV_ORDER);
     c->tm.score_total_ms = ev_ms(c, EV_SCORE_TOTAL);
     c->scored = true;
+}
+
+// ---- multi-GPU scoring ------------------------------------------------------------------------------------------
+void pdl_run_dist_score_begin(pdl_ctx *c) {
+    hipStream_t st = c->stream;
+    ev_begin(c, EV_SCORE_TOTAL);
+    if (!c->tasks_ready) pdl_prepare_tasks(c);
+    score_reset(c);
+    const uint32_t W = c->world, n_rows = c->n_task_rows;
+    if (W > PDL_MAX_WORLD) PDL_FAIL(PDL_ERR_UNSUPPORTED, "more than %u ranks", PDL_MAX_WORLD);
+    c->h_outbox_counts.assign(W, 0);
+    c->st_local = 0; c->n_inbox = 0;
+    uint64_t upper = 0;
+    for (uint32_t g : c->shard) upper += c->h_upper_cost[g];
+    c->tm.walked_lookups = upper;
+    if (n_rows == 0) { ev_end(c, EV_SCORE_TOTAL); PDL_HIP(hipStreamSynchronize(st)); c->dist_stage = 3; return; }
+    const ScorePlan pl = score_plan(c);
+    if (!pl.mirror) PDL_FAIL(PDL_ERR_STATE, "multi-GPU scoring needs the upper-triangle range lists of pdl_dist_preprocess_finish");
+    score_alloc_rows(c, pl);
+    uint64_t *d_scal = c->scalars.as<uint64_t>();
+    uint32_t *ctr32 = c->join_ctr.as<uint32_t>();
+    // outbox listing: rows are dealt to workgroups in blocks
+    const uint32_t n_blocks = std::max<uint32_t>(1, std::min<uint32_t>((n_rows + 15) / 16, 2048));
+    const uint32_t rows_per_block = (n_rows + n_blocks - 1) / n_blocks;
+    const size_t tab_n = (size_t) W * n_blocks;
+    c->outbox_tab.alloc((2 * tab_n + W + 2) * sizeof(uint32_t));
+    uint32_t *tab = c->outbox_tab.as<uint32_t>(), *offs = tab + tab_n, *d_tot = offs + tab_n;
+    unsigned long long cap = first_staging_cap(c, pl, std::max<uint64_t>(upper, 1));
+    for (int attempt = 0; attempt < 2; attempt++) {
+        // room for as many received cells as staged ones right away (the exchange is symmetric on average); grown if short
+        score_alloc_cells(c, pl, cap, cap, false);
+        score_join(c, pl);
+        OutboxArgs oa{};
+        oa.row_base = c->row_base.as<uint32_t>(); oa.row_cnt = c->row_cnt.as<uint32_t>(); oa.task_rows = c->task_rows.as<uint32_t>();
+        oa.st_score = c->st_score.as<float>(); oa.st_perc = c->st_perc.as<float>(); oa.st_tr = c->st_tr.as<float>();
+        oa.st_col = c->st_col.as<uint32_t>(); oa.st_first = c->st_first.as<uint32_t>();
+        oa.taskpos_of = c->taskpos_of.as<uint32_t>(); oa.genome_of = c->d_gen; oa.owner = c->owner_of_genome.as<uint32_t>();
+        oa.n_rows = n_rows; oa.rows_per_block = rows_per_block; oa.world = W; oa.n_blocks = n_blocks;
+        oa.tab = tab; oa.offs = offs;
+        hipLaunchKernelGGL(k_outbox<false>, dim3(n_blocks), dim3(256), 0, st, oa);
+        scan_and_apply(c, tab_n, RowCntFlag{tab, nullptr}, FinOffApply{offs}, d_scal + 12);
+        hipLaunchKernelGGL(k_outbox_totals, dim3(1), dim3(PDL_MAX_WORLD + 1 < 128 ? 128 : PDL_MAX_WORLD + 1), 0, st, offs, n_blocks, W, d_scal + 12, d_tot);
+        PDL_HIP(hipGetLastError());
+        uint32_t h_tot[PDL_MAX_WORLD + 1];
+        uint32_t h_ctr[8];
+        {
+            PinRead rd(c);
+            const uint32_t *pt = rd.add<uint32_t>(d_tot, W + 1);
+            const uint32_t *pc = rd.add<uint32_t>(ctr32, 8);
+            rd.sync();
+            memcpy(h_tot, pt, (W + 1) * 4); memcpy(h_ctr, pc, sizeof(h_ctr));
+        }
+        if (h_ctr[6]) PDL_FAIL(PDL_ERR_DEVICE, "join: %u internal consistency violations", h_ctr[6]);
+        unsigned long long z;
+        memcpy(&z, &h_ctr[4], sizeof(z));
+        if (z > cap) {
+            if (attempt == 1) PDL_FAIL(PDL_ERR_DEVICE, "staging overflow persisted (%llu cells > %llu)", z, cap);
+            cap = z + pl.slack;
+            continue;
+        }
+        const uint64_t total = h_tot[W];
+        for (uint32_t d = 0; d < W; d++) c->h_outbox_counts[d] = (d + 1 < W ? h_tot[d + 1] : total) - h_tot[d];
+        c->outbox.alloc(std::max<uint64_t>(total, 1) * sizeof(pdl_dist_cell));
+        if (total) {
+            oa.out = c->outbox.as<pdl_dist_cell>();
+            hipLaunchKernelGGL(k_outbox<true>, dim3(n_blocks), dim3(256), 0, st, oa);
+            PDL_HIP(hipGetLastError());
+        }
+        c->tm.outbox_cells = total;
+        break;
+    }
+    ev_end(c, EV_SCORE_TOTAL);
+    PDL_HIP(hipStreamSynchronize(st));
+    c->tm.join_ms = ev_ms(c, EV_JOIN);
+    c->tm.join_overflow_ms = ev_ms(c, EV_JOIN_OVF);
+    c->tm.dist_score_begin_ms = ev_ms(c, EV_SCORE_TOTAL);
+    c->dist_stage = 3;
+}
+
+void pdl_run_dist_score_finish(pdl_ctx *c, const pdl_dist_cell *d_inbox, uint64_t n_inbox) {
+    hipStream_t st = c->stream;
+    ev_begin(c, EV_DIST_SCORE_FINISH);
+    const uint32_t n_rows = c->n_task_rows;
+    c->tm.inbox_cells = n_inbox;
+    if (n_rows == 0) {
+        if (n_inbox) PDL_FAIL(PDL_ERR_ARGUMENT, "%llu cells received by a rank without rows", (unsigned long long) n_inbox);
+        ev_end(c, EV_DIST_SCORE_FINISH); c->scored = true; c->dist_stage = 4; return;
+    }
+    const ScorePlan pl = score_plan(c);
+    const unsigned long long cap = c->st_cap;
+    if (n_inbox > cap) score_alloc_cells(c, pl, cap, n_inbox, true);       // (rare: the first allocation leaves room for `cap` received cells)
+    else if (2 * cap + n_inbox >= 0xffffffffull) PDL_FAIL(PDL_ERR_UNSUPPORTED, "more than 2^32 emitted cells on one device");
+    if (n_inbox) {
+        InboxArgs ia{};
+        ia.in = d_inbox; ia.n = (uint32_t) n_inbox; ia.slot0 = (uint32_t) cap;
+        ia.st_score = c->st_score.as<float>(); ia.st_perc = c->st_perc.as<float>(); ia.st_tr = c->st_tr.as<float>();
+        ia.st_col = c->st_col.as<uint32_t>(); ia.st_first = c->st_first.as<uint32_t>(); ia.st_src = c->st_src.as<uint32_t>();
+        ia.taskpos_of = c->taskpos_of.as<uint32_t>(); ia.genome_of = c->d_gen; ia.local_genome = c->local_genome.as<uint32_t>();
+        ia.mirror_cnt = c->mirror_cnt.as<uint32_t>(); ia.MS = c->MS.as<float>(); ia.CM = c->CM.as<float>();
+        ia.N = c->N; ia.G = c->G; ia.error_count = c->join_ctr.as<uint32_t>() + 6;
+        hipLaunchKernelGGL(k_inbox_file, dim3((uint32_t) ((n_inbox + 255) / 256)), dim3(256), 0, st, ia);
+        PDL_HIP(hipGetLastError());
+    }
+    const unsigned long long z = score_order(c, pl, (uint32_t) n_inbox, EV_DIST_SCORE_FINISH);
+    if (z > cap) PDL_FAIL(PDL_ERR_DEVICE, "staging cursor moved after the join (%llu > %llu)", z, cap);
+    c->tm.order_ms = ev_ms(c, EV_ORDER);
+    c->tm.dist_score_finish_ms = ev_ms(c, EV_DIST_SCORE_FINISH);
+    c->tm.score_total_ms = c->tm.dist_score_begin_ms + c->tm.dist_score_finish_ms;
+    c->scored = true;
+    c->dist_stage = 4;
 }

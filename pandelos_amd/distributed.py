@@ -1,17 +1,26 @@
-"""Multi-GPU sharding of the scoring path — one process per GPU.
+"""Multi-GPU driver of the hot path — one process per GPU, bytes moved by RCCL over xGMI.
 
-The unit of work is the reference's per-genome task (``generateScoresPart(g)``, Pangenes.java:60-66):
-tasks are independent given the dictionary and their outputs (cells, per-row and per-column maxima)
-need no cross-rank reduction, so genomes are dealt to ranks once, before the dictionary build, by
-longest-processing-time on a cost proxy that is known up front (residues per genome; the reference's
-own per-genome cost needs the dictionary).  Each rank then
+The reference runs its per-genome tasks on a thread pool over ONE dictionary in shared memory
+(``Pangenes.java:54-66``, ``library.cpp:73``).  Here every GPU ends up with the whole dictionary in
+its own HBM and scores a disjoint set of genomes; what the shared memory did is done by two exchanges:
 
-  * builds the dictionary postings (round-1 status: every rank builds all of them itself),
-  * builds posting-range lists / costs only for ITS genes (``pdl_set_genome_shard`` before
-    ``pdl_preprocess``), and scores only its genomes.
+  dictionary   every rank ranks all k-mers (the input is on every host), keeps one interval of the
+               rank space, sorts + dedups it (``pdl_dist_preprocess_begin``): 1/W of the reference's
+               ``library.cpp:270-287``.  The runs are all-gathered *in place* into one device array —
+               W−1 sends and W−1 receives per rank, posted together, so each of the 7 xGMI links of a
+               GPU carries one peer's run (no ring, no merge: the concatenation in rank order is the
+               dictionary).  ``pdl_dist_preprocess_finish`` builds groups, deals the genomes
+               (longest-processing-time on exact lookup counts, identical on every rank) and this
+               rank's posting-range lists.
+  cells        rows only meet the genes above them (half the lookups, as on one GPU); a cell whose
+               column is another rank's row travels there: one variable-size all-to-all of 24-byte
+               cells (``pdl_dist_score_begin`` / ``pdl_dist_score_finish``).
 
-Collectives (``torch.distributed``: RCCL on GPUs, gloo in the CPU tests) carry only the scalar
-totals that a whole-job report needs.
+``DistributedPangenes`` is one rank of a ``torch.distributed`` group ("nccl" = RCCL on ROCm; "gloo"
+stages through host memory and is what the CPU-side tests and the one-GPU rehearsal use).
+``LocalRanks`` runs W ranks inside one process on one device with device-to-device copies in place of
+the collectives: the same library calls in the same order, used by the parity tests and by
+``tools/shard_step_time.py`` to time each rank's share on a single MI355X.
 """
 from __future__ import annotations
 
@@ -19,7 +28,10 @@ from typing import List, Sequence
 
 import numpy as np
 
+from . import _lib
 
+
+# ---- partition helpers (host only) ---------------------------------------------------------------------
 def residues_per_genome(offsets: np.ndarray, genome_of: np.ndarray, genomes: int) -> np.ndarray:
     lens = np.diff(np.asarray(offsets, dtype=np.uint64)).astype(np.float64)
     return np.bincount(np.asarray(genome_of, dtype=np.int64), weights=lens, minlength=genomes)
@@ -27,7 +39,8 @@ def residues_per_genome(offsets: np.ndarray, genome_of: np.ndarray, genomes: int
 
 def lpt_shards(weights: Sequence[float], n: int) -> List[List[int]]:
     """Longest-processing-time assignment of genomes to n ranks; every list ascending.  Deterministic, so
-    every rank computes the same partition without talking to the others."""
+    every rank computes the same partition without talking to the others (the library does the same on
+    exact lookup counts, ``pdl_dist_genome_owner``)."""
     order = np.argsort(-np.asarray(weights, dtype=np.float64), kind="stable")
     loads = [0.0] * n
     shards: List[List[int]] = [[] for _ in range(n)]
@@ -43,6 +56,13 @@ def shard_for_rank(offsets, genome_of, world: int, rank: int) -> List[int]:
     return lpt_shards(residues_per_genome(offsets, genome_of, genomes), world)[rank]
 
 
+def exclusive_offsets(counts: Sequence[int]) -> np.ndarray:
+    out = np.zeros(len(counts) + 1, np.int64)
+    np.cumsum(np.asarray(counts, dtype=np.int64), out=out[1:])
+    return out
+
+
+# ---- small collectives on scalars ---------------------------------------------------------------------
 def all_reduce_sum(values: Sequence[float], device=None) -> List[float]:
     """Sum a few scalars over all ranks (no-op without an initialised process group)."""
     import torch
@@ -81,3 +101,163 @@ def gather_genome_owner(shard: Sequence[int], genomes: int, device=None) -> np.n
     if not bool((hits == 1).all()):
         raise RuntimeError("genome shards are not a partition of the genomes")
     return mine.cpu().numpy()
+
+
+# ---- one rank of a torch.distributed group -----------------------------------------------------------------
+class DistributedPangenes:
+    """The hot path on rank ``dist.get_rank()`` of an initialised process group.
+
+    ``device_collectives`` (backend "nccl"): the exchange buffers are device tensors handed to RCCL.
+    Otherwise ("gloo") they are staged through host tensors — same calls, same order."""
+
+    def __init__(self, nat, device, device_collectives: bool):
+        import torch.distributed as dist
+        self.nat = nat
+        self.dev = device
+        self.on_device = device_collectives
+        self.world = dist.get_world_size()
+        self.rank = dist.get_rank()
+        self.exchange_s = {"dictionary": 0.0, "cells": 0.0}
+
+    # exchange of the dictionary runs: full[offs[p] : offs[p+1]] <- rank p's run, for every p
+    def _all_gather_runs(self, full, offs):
+        import torch
+        import torch.distributed as dist
+        r, W = self.rank, self.world
+        if self.on_device:
+            ops = []
+            mine = full[offs[r]:offs[r + 1]]
+            for step in range(1, W):        # peer order staggered per rank: every link is busy from the start
+                dst, src = (r + step) % W, (r - step) % W
+                if offs[r + 1] > offs[r]:
+                    ops.append(dist.P2POp(dist.isend, mine, dst))
+                if offs[src + 1] > offs[src]:
+                    ops.append(dist.P2POp(dist.irecv, full[offs[src]:offs[src + 1]], src))
+            if ops:
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+        else:
+            host = torch.empty(int(offs[-1]), dtype=torch.int64)
+            host[offs[r]:offs[r + 1]] = full[offs[r]:offs[r + 1]].cpu()
+            for p in range(W):
+                if offs[p + 1] > offs[p]:
+                    dist.broadcast(host[offs[p]:offs[p + 1]], src=p)
+            full.copy_(host)
+
+    def preprocess(self, k, t_res, t_off, t_gen, n_genes, n_residues):
+        import time
+        import torch
+        import torch.distributed as dist
+        nat, W, r = self.nat, self.world, self.rank
+        ptr, records, _ = nat.dist_preprocess_begin(k, t_res.data_ptr(), t_off.data_ptr(), t_gen.data_ptr(), n_genes, n_residues,
+                                                    W, r, keepalive=(t_res, t_off, t_gen))
+        t0 = time.perf_counter()
+        cnt = torch.tensor([records], dtype=torch.int64, device=self.dev if self.on_device else None)
+        allc = torch.empty(W, dtype=torch.int64, device=cnt.device)
+        dist.all_gather_into_tensor(allc, cnt)
+        offs = exclusive_offsets(allc.cpu().numpy())
+        total = int(offs[-1])
+        full = torch.empty(max(total, 1), dtype=torch.int64, device=self.dev)      # 8-byte records {gene, count|flag}
+        if records:
+            nat.copy_device(full.data_ptr() + int(offs[r]) * 8, ptr, records * 8)
+        self._all_gather_runs(full, offs)
+        if self.on_device:
+            torch.cuda.current_stream(self.dev).synchronize()
+        self.exchange_s["dictionary"] = time.perf_counter() - t0
+        nat.dist_preprocess_finish(full.data_ptr(), total, keepalive=full)
+        return nat.cost
+
+    def score_all(self):
+        import time
+        import torch
+        import torch.distributed as dist
+        nat, W = self.nat, self.world
+        ptr, send_counts = nat.dist_score_begin(W)
+        t0 = time.perf_counter()
+        cdev = self.dev if self.on_device else None
+        sc = torch.as_tensor(send_counts, dtype=torch.int64, device=cdev)
+        rc = torch.empty(W, dtype=torch.int64, device=cdev)
+        dist.all_to_all_single(rc, sc)
+        recv_counts = rc.cpu().numpy()
+        n_out, n_in = int(send_counts.sum()), int(recv_counts.sum())
+        send = torch.empty((max(n_out, 1), 6), dtype=torch.int32, device=self.dev)     # pdl_dist_cell = 6 x 4 bytes
+        recv = torch.empty((max(n_in, 1), 6), dtype=torch.int32, device=self.dev)
+        if n_out:
+            nat.copy_device(send.data_ptr(), ptr, n_out * _lib.DIST_CELL_BYTES)
+        if self.on_device:
+            dist.all_to_all_single(recv[:n_in], send[:n_out], output_split_sizes=[int(x) for x in recv_counts],
+                                   input_split_sizes=[int(x) for x in send_counts])
+            torch.cuda.current_stream(self.dev).synchronize()
+        else:
+            h_recv = torch.empty((n_in, 6), dtype=torch.int32)
+            dist.all_to_all_single(h_recv, send[:n_out].cpu(), output_split_sizes=[int(x) for x in recv_counts],
+                                   input_split_sizes=[int(x) for x in send_counts])
+            recv[:n_in].copy_(h_recv)
+            torch.cuda.synchronize(self.dev)
+        self.exchange_s["cells"] = time.perf_counter() - t0
+        nat.dist_score_finish(recv.data_ptr(), n_in, keepalive=recv)
+
+    def my_genomes(self) -> List[int]:
+        owner = self.nat.dist_genome_owner()
+        return [int(g) for g in np.nonzero(owner == self.rank)[0]]
+
+
+# ---- W ranks inside one process on one device -----------------------------------------------------------------
+class LocalRanks:
+    """W contexts on ONE device driven in lockstep; device-to-device copies stand in for the collectives.
+
+    Same library calls in the same order as ``DistributedPangenes``; per-rank device times come from the
+    contexts' own HIP-event timings (``tools/shard_step_time.py``)."""
+
+    def __init__(self, world: int, device: int = -1, stream=None, flags: int = 0):
+        from .pangene_native import PangeneNative
+        self.world = world
+        self.ranks = [PangeneNative.open(device=device, stream=stream, flags=flags) for _ in range(world)]
+
+    def close(self):
+        for n in self.ranks:
+            n.close()
+
+    def preprocess(self, k, t_res, t_off, t_gen, n_genes, n_residues):
+        import torch
+        W = self.world
+        runs = [n.dist_preprocess_begin(k, t_res.data_ptr(), t_off.data_ptr(), t_gen.data_ptr(), n_genes, n_residues, W, r,
+                                        keepalive=(t_res, t_off, t_gen)) for r, n in enumerate(self.ranks)]
+        offs = exclusive_offsets([rec for _, rec, _ in runs])
+        total = int(offs[-1])
+        self.run_records = [rec for _, rec, _ in runs]
+        self.dictionaries = []
+        for r, n in enumerate(self.ranks):
+            full = torch.empty(max(total, 1), dtype=torch.int64, device=t_res.device)
+            for p, (ptr, rec, _) in enumerate(runs):      # "all-gather": every rank's copy of every run
+                if rec:
+                    n.copy_device(full.data_ptr() + int(offs[p]) * 8, ptr, rec * 8)
+            self.dictionaries.append(full)
+        for n, full in zip(self.ranks, self.dictionaries):
+            n.dist_preprocess_finish(full.data_ptr(), total, keepalive=full)
+        self.owner = self.ranks[0].dist_genome_owner()
+        for n in self.ranks[1:]:
+            assert np.array_equal(n.dist_genome_owner(), self.owner), "ranks disagree on the genome deal"
+        return self.ranks[0].cost
+
+    def score_all(self):
+        import torch
+        W = self.world
+        boxes = [n.dist_score_begin(W) for n in self.ranks]
+        self.outbox_counts = np.stack([c for _, c in boxes])               # [src][dst]
+        dev = self.dictionaries[0].device
+        for d, n in enumerate(self.ranks):                                  # "all-to-all": column d of the count matrix
+            n_in = int(self.outbox_counts[:, d].sum())
+            recv = torch.empty((max(n_in, 1), 6), dtype=torch.int32, device=dev)
+            at = 0
+            for s in range(W):
+                cnt = int(self.outbox_counts[s, d])
+                if cnt:
+                    src_off = int(self.outbox_counts[s, :d].sum())
+                    n.copy_device(recv.data_ptr() + at * _lib.DIST_CELL_BYTES, boxes[s][0] + src_off * _lib.DIST_CELL_BYTES,
+                                  cnt * _lib.DIST_CELL_BYTES)
+                    at += cnt
+            n.dist_score_finish(recv.data_ptr(), n_in, keepalive=recv)
+
+    def generate_scores_part(self, genome: int):
+        return self.ranks[int(self.owner[genome])].generate_scores_part(genome)

@@ -138,6 +138,45 @@ class PangeneNative:
     def score_all(self) -> None:
         self._check(self._lib.pdl_score_all(self._ctx))
 
+    def set_option(self, name: str, value: int) -> None:
+        """Tuning / test switch of this context (``pdl_set_option``; the library reads no environment variable)."""
+        self._check(self._lib.pdl_set_option(self._ctx, name.encode(), int(value)))
+
+    # -- multi-GPU passes (one context per GPU; pandelos_amd.distributed moves the bytes in between) ------------
+    def dist_preprocess_begin(self, k, d_residues: int, d_offsets: int, d_genome_of: int, n_sequences: int,
+                              n_residues: int, world: int, rank: int, keepalive=None):
+        """-> (device pointer, records, k-mers) of this rank's run of the dictionary."""
+        self._keep = keepalive
+        sl = _lib.PdlDistSlice()
+        self._check(self._lib.pdl_dist_preprocess_begin(self._ctx, d_residues, d_offsets, d_genome_of, n_sequences, n_residues,
+                                                        int(k), int(world), int(rank), C.byref(sl)))
+        return sl.d_postings or 0, int(sl.records), int(sl.kmers)
+
+    def dist_preprocess_finish(self, d_postings_all: int, total_records: int, keepalive=None) -> None:
+        self._keep_dict = keepalive
+        self.cost = _lib.PdlCost()
+        self._check(self._lib.pdl_dist_preprocess_finish(self._ctx, d_postings_all, int(total_records), C.byref(self.cost)))
+
+    def dist_genome_owner(self) -> np.ndarray:
+        out = np.zeros(self.cost.genomes, np.uint32)
+        self._check(self._lib.pdl_dist_genome_owner(self._ctx, out.ctypes.data))
+        return out
+
+    def dist_score_begin(self, world: int):
+        """-> (device pointer of the outbox, cells per destination rank [world])."""
+        ob = _lib.PdlDistOutbox()
+        self._check(self._lib.pdl_dist_score_begin(self._ctx, C.byref(ob)))
+        counts = np.array([ob.counts[d] for d in range(world)], dtype=np.int64)
+        assert int(counts.sum()) == ob.total
+        return ob.d_cells or 0, counts
+
+    def dist_score_finish(self, d_inbox: int, n_inbox: int, keepalive=None) -> None:
+        self._keep_inbox = keepalive
+        self._check(self._lib.pdl_dist_score_finish(self._ctx, d_inbox, int(n_inbox)))
+
+    def copy_device(self, d_dst: int, d_src: int, nbytes: int) -> None:
+        self._check(self._lib.pdl_copy_device(self._ctx, d_dst, d_src, int(nbytes)))
+
     def set_genome_shard(self, genomes: Sequence[int]) -> None:
         g = np.ascontiguousarray(genomes, dtype=np.uint32)
         self._check(self._lib.pdl_set_genome_shard(self._ctx, g.ctypes.data, len(g)))

@@ -1,0 +1,164 @@
+"""Multi-GPU path on the device (pdl_dist_*): W ranks build the dictionary co-operatively (rank intervals), deal the
+genomes, score only above the diagonal and exchange the mirrored cells.  Every genome's Scores block must equal the
+reference's fixture bit for bit, whatever W is and whichever rank scored it.
+
+  * LocalRanks: W contexts in one process on one device, device copies in place of the collectives (same library calls
+    in the same order as the torch.distributed driver);
+  * two real processes over torch.distributed (gloo, both on cuda:0): the driver itself, collectives included."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _device_inputs(res, off, gen):
+    import torch
+    dev = torch.device("cuda", 0)
+    pad = (-len(res)) % 16 + 16
+    t_res = torch.from_numpy(np.concatenate([res, np.zeros(pad, np.uint8)])).to(dev)
+    t_off = torch.from_numpy(off.astype(np.int64)).to(dev)
+    t_gen = torch.from_numpy(gen.astype(np.int32)).to(dev)
+    return t_res, t_off, t_gen
+
+
+def _local(world, res, off, gen, k, flags=0):
+    from pandelos_amd.distributed import LocalRanks
+    t = _device_inputs(res, off, gen)
+    lr = LocalRanks(world, flags=flags)
+    cost = lr.preprocess(k, *t, len(gen), len(res))
+    return lr, cost
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 5])
+@pytest.mark.parametrize("name", ["synth_5x60x80_k3", "synth_5x60x80_k13", "synth_5x60x80_k16_hash", "low_complexity", "q1_fold",
+                                  "q1_fold_onto_singleton", "q1_fold_same_gene_twice", "readme4_k1", "readme4_k2",
+                                  "short_and_duplicate_genes", "interleaved_genomes"])
+def test_ranks_together_reproduce_the_fixture(name, world):
+    res, off, gen, k, fx = H.load_small(name)
+    lr, cost = _local(world, res, off, gen, k)
+    assert cost.total_cost == int(fx["total_cost"]) and (cost.sequences, cost.genomes) == (int(fx["sequences"]), int(fx["genomes"]))
+    assert sum(lr.run_records) == cost.dictionary_records
+    for n in lr.ranks:                                   # every rank knows every genome's cost (library.cpp:535-538)
+        assert [n.genome_cost(g) for g in range(cost.genomes)] == [int(x) for x in fx["genome_cost"]]
+        assert (n.cost.groups, n.cost.shared_records) == (cost.groups, cost.shared_records)
+    lr.score_all()
+    assert all(int(x) < world for x in lr.owner)
+    H.assert_scores_equal_fixture(lambda g: lr.generate_scores_part(g).as_dict(), fx, cost.genomes, f"{name} W={world}")
+    # what travelled: cells whose row and column live on different ranks, each once (the upper one)
+    sent = int(lr.outbox_counts.sum())
+    cross = 0
+    for g in range(cost.genomes):
+        col_owner = lr.owner[fx[f"g{g}_second_seq_genome"]]
+        cross += int((col_owner != lr.owner[g]).sum())
+    assert 2 * sent == cross
+    lr.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_together_reproduce_the_reference_digest(world):
+    res, off, gen, k, d = H.load_large("synth_16x1000x300_k5")
+    lr, cost = _local(world, res, off, gen, k)
+    assert cost.total_cost == d["total_cost"]
+    lr.score_all()
+    H.assert_scores_match_digest(lambda g: lr.generate_scores_part(g).as_dict(), d, f"W={world}")
+    # the deal balances what the join walks (lookups above the diagonal), within one genome's worth
+    walked = [n.timings()["walked_lookups"] for n in lr.ranks]
+    assert sum(walked) * 2 == cost.total_cost - cost.shared_records
+    assert max(walked) - min(walked) <= max(walked) / 2
+    lr.close()
+
+
+def test_canonical_order_and_tiny_staging_under_sharding():
+    from pandelos_amd import _lib
+    res, off, gen, k, fx = H.load_small("synth_5x60x80_k3")
+    lr, cost = _local(3, res, off, gen, k, flags=_lib.PDL_FLAG_CANONICAL_ORDER)
+    for n in lr.ranks:
+        n.set_option("staging_cap", 8)                   # the first attempt of every rank overflows and is repeated
+    lr.score_all()
+    for g in range(cost.genomes):
+        got = lr.generate_scores_part(g).as_dict()
+        order = np.lexsort((fx[f"g{g}_column"], fx[f"g{g}_row"]))
+        for f in ("scores", "percs", "tr_percs", "row", "column"):
+            assert np.array_equal(H.raw(got[f]), fx[f"g{g}_{f}"][order]), f"genome {g} {f}"
+        for f in ("max_genome_score", "max_genome_score_col", "scoresMaxMappings"):
+            assert np.array_equal(H.raw(got[f]), fx[f"g{g}_{f}"]), f"genome {g} {f}"
+    lr.close()
+
+
+@pytest.mark.parametrize("seed", list(range(5000, 5020)))
+def test_random_sets_sharded_match_the_oracle(seed):
+    from oracle import binding as ob
+    from tests.test_gpu_fuzz import _random_set
+    res, off, gen, k = _random_set(seed)
+    if int((np.diff(off.astype(np.int64)) >= k).sum()) == 0:
+        pytest.skip("no gene holds a k-mer (undefined in the reference)")
+    ora = ob.Oracle(res, off, gen, k)
+    world = 2 + seed % 3
+    lr, cost = _local(world, res, off, gen, k)
+    assert cost.total_cost == ora.total_cost
+    lr.score_all()
+    for g in range(ora.genomes):
+        H.assert_scores_equal(lr.generate_scores_part(g).as_dict(), ora.scores(g), f"seed {seed} W={world} genome {g}")
+    lr.close()
+
+
+# ---- the torch.distributed driver, two processes on one GPU ---------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rank_main(rank, world, port, name, out):
+    import torch
+    import torch.distributed as dist
+    from pandelos_amd.distributed import DistributedPangenes
+    from pandelos_amd.pangene_native import PangeneNative
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        res, off, gen, k, d = H.load_large(name)
+        t = _device_inputs(res, off, gen)
+        dp = DistributedPangenes(PangeneNative.open(), torch.device("cuda", 0), device_collectives=False)
+        cost = dp.preprocess(k, *t, len(gen), len(res))
+        dp.score_all()
+        mine = dp.my_genomes()
+        import hashlib
+        digests = {}
+        for g in mine:
+            got = dp.nat.generate_scores_part(g).as_dict()
+            digests[g] = (int(got["scoresCount"]), {f: hashlib.sha256(H.raw(got[f]).tobytes()).hexdigest() for f in H.FIELDS})
+        out.put((rank, int(cost.total_cost), digests))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_processes_over_torch_distributed_reproduce_the_digest():
+    import torch.multiprocessing as mp
+    name = "synth_8x300x200_k4_div25"
+    d = H.DIGESTS[name]
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, name, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [out.get(timeout=500) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    seen = {}
+    for rank, total_cost, digests in got:
+        assert total_cost == d["total_cost"]
+        assert digests, f"rank {rank} scored nothing"
+        seen.update(digests)
+    assert sorted(seen) == list(range(d["genomes"]))
+    for g, (z, sha) in seen.items():
+        assert z == d["scoresCount"][g] and sha == d["sha256"][g], f"genome {g}"

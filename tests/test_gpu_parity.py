@@ -54,6 +54,14 @@ def test_dictionary_stage_matches_oracle(name):
     assert np.array_equal(ranks, d["rank"]) and np.array_equal(seqs, d["seq"]) and np.array_equal(counts, d["count"])
     cost, kl = nat.sequence_costs()
     assert np.array_equal(cost, ora.total_visited()) and np.array_equal(kl, ora.kseq_lengths())
+    # rank-groups of >= 2 records as the reference's scan forms them (library.cpp:297-306: the last record never opens one)
+    rk = np.sort(d["rank"])                          # (the fold moved the last record inside its group: back to rank order)
+    heads = np.flatnonzero(np.r_[True, rk[1:-1] != rk[:-2]]) if len(d) > 1 else np.array([0])
+    sizes = np.diff(np.r_[heads, max(len(d) - 1, 1)]).astype(np.int64)
+    if len(d) > 1:
+        sizes[-1] += 1
+    assert nat.cost.groups == int((sizes >= 2).sum()) and nat.cost.shared_records == int(sizes[sizes >= 2].sum())
+    assert nat.cost.total_cost == int((sizes[sizes >= 2] ** 2).sum())
 
 
 @pytest.mark.parametrize("shape,k", [
@@ -92,15 +100,39 @@ def test_wide_rows_keep_the_reference_emission_order(genomes, per_genome, floor)
     assert widest > floor
 
 
-def test_per_genome_device_copies_equal_the_host_mirror(monkeypatch):
+def test_per_genome_device_copies_equal_the_host_mirror():
     """pdl_compute_scores slices a pinned host mirror of the whole result (<= 1 GiB) or, for larger results, copies each
-    genome's block from the device; PDL_HOST_MIRROR=0 forces the second path."""
+    genome's block from the device through per-thread pinned bounce buffers; option host_mirror=0 forces the second path."""
     res, off, gen, k, fx = H.load_small(H.SMALL_CASES[0])
     nat = _native(res, off, gen, k)
     H.assert_scores_equal_fixture(lambda g: nat.generate_scores_part(g).as_dict(), fx, nat.cost.genomes, "mirror")
-    monkeypatch.setenv("PDL_HOST_MIRROR", "0")
     nat2 = _native(res, off, gen, k)
+    nat2.set_option("host_mirror", 0)
     H.assert_scores_equal_fixture(lambda g: nat2.generate_scores_part(g).as_dict(), fx, nat2.cost.genomes, "device copies")
+
+
+def test_concurrent_callers_without_the_host_mirror_match_the_digest():
+    """The reference's pool calls computeScores from ThreadsNum threads at once (Pangenes.java:54-66).  Here: eight threads,
+    the device-copy path (blocks of several MB: more than one bounce-buffer chunk), every block against the reference's digest."""
+    from concurrent.futures import ThreadPoolExecutor
+    res, off, gen, k, d = H.load_large("synth_16x1000x300_k5")
+    nat = _native(res, off, gen, k)
+    nat.set_option("host_mirror", 0)
+    with ThreadPoolExecutor(8) as ex:
+        blocks = list(ex.map(lambda g: nat.generate_scores_part(g).as_dict(), range(d["genomes"])))
+    H.assert_scores_match_digest(lambda g: blocks[g], d, "8 threads, device copies")
+
+
+@pytest.mark.parametrize("name", ["synth_5x60x80_k3", "low_complexity"])
+def test_staging_overflow_repeats_the_pass(name):
+    """A staging area that is too small for the emitted cells makes the join report the size it needs and the pass is
+    repeated once; rows that did not fit hold no cell in the first attempt, so K-order stays inside its buffers."""
+    res, off, gen, k, fx = H.load_small(name)
+    nat = _native(res, off, gen, k)
+    nat.set_option("staging_cap", 16)           # far below the cells of one row
+    H.assert_scores_equal_fixture(lambda g: nat.generate_scores_part(g).as_dict(), fx, nat.cost.genomes, f"{name} tiny staging")
+    nat.set_option("join_tiny_tier2", 1)        # the HBM-table kernel reserves exact sizes: same rule
+    H.assert_scores_equal_fixture(lambda g: nat.generate_scores_part(g).as_dict(), fx, nat.cost.genomes, f"{name} tiny staging, HBM tier")
 
 
 def test_errors_mirror_reference_behaviour():
@@ -177,23 +209,23 @@ def test_canonical_order_flag_gives_same_cells_sorted_by_column():
 
 
 @pytest.mark.parametrize("name", ["synth_5x60x80_k3", "low_complexity", "q1_fold_same_gene_twice", "readme4_k1"])
-def test_hbm_table_path_matches_fixture(name, monkeypatch):
+def test_hbm_table_path_matches_fixture(name):
     """Rows whose candidate set does not fit the LDS table are redone by k_join_hbm.  A deliberately tiny
-    LDS table (PDL_JOIN_TABLE_BITS=9: 512 slots, 64 ranges staged per batch) exercises the multi-batch staging
+    LDS table (option join_tiny_tier2: 512 slots, 64 ranges staged per batch) exercises the multi-batch staging
     and, where a row has more than 384 candidates, that path."""
-    monkeypatch.setenv("PDL_JOIN_TABLE_BITS", "9")
     res, off, gen, k, fx = H.load_small(name)
     nat = _native(res, off, gen, k)
+    nat.set_option("join_tiny_tier2", 1)
     H.assert_scores_equal_fixture(lambda g: nat.generate_scores_part(g).as_dict(), fx, nat.cost.genomes, name)
 
 
-def test_hbm_table_path_matches_oracle_on_dense_set(monkeypatch):
+def test_hbm_table_path_matches_oracle_on_dense_set():
     """k=2 on 1500 genes: every gene shares k-mers with every other one (candidate sets ~ N)."""
     from oracle import binding as ob
     from pandelos_amd.synth import make_gene_set
-    monkeypatch.setenv("PDL_JOIN_TABLE_BITS", "9")
     gs = make_gene_set(genomes=10, genes_per_genome=150, mean_len=60, sub_rate=0.3, seed=205)
     nat = _native(gs.residues, gs.offsets, gs.genome_of, 2)
+    nat.set_option("join_tiny_tier2", 1)
     ora = ob.Oracle(gs.residues, gs.offsets, gs.genome_of, 2)
     for g in range(ora.genomes):
         H.assert_scores_equal(nat.generate_scores_part(g).as_dict(), ora.scores(g), f"genome {g}")

@@ -2,35 +2,42 @@
 """bench.py — scored gene-pairs/s of the PanDelos hot path on MI355X (BASELINE.json metric).
 
 One *step* = one complete pass of the hot path over the workload, inputs already resident in HBM:
-    pdl_preprocess_device   K-hist, K-rank, K-sort, K-rle, K-groups, K-ranges   (library.cpp:189-371)
-    pdl_score_all           K-join (+HBM-table pass for overflow rows), K-order (library.cpp:409-527)
-Outputs (all per-genome Scores blocks) stay in HBM; the PCIe-inclusive rate is reported in DESIGN.md.
+    N = 1   pdl_preprocess_device   K-hist, K-rank, K-sort, K-rle, K-groups, K-ranges   (library.cpp:189-371)
+            pdl_score_all           K-join (+HBM-table pass for overflow rows), K-order (library.cpp:409-527)
+    N > 1   pandelos_amd.distributed.DistributedPangenes, one rank per GPU: rank-interval dictionary build,
+            all-gather of the runs (RCCL send/recv, one peer per xGMI link), genome deal, upper-triangle join,
+            all-to-all of the mirrored cells, K-order.  Same dataset at every N: "scaling": "strong".
+Outputs (all per-genome Scores blocks) stay in HBM; `host_path` in the same line is SURVEY.md §8d's wall time
+(host arrays in -> every Scores block on the host, PCIe both ways) measured by this run at N = 1.
 
-Workload at N=1: BASELINE.json configs[2], the canonical 64-genome set.  The real 64-Mycoplasma
-.faa cannot be fetched offline, so the stand-in of BASELINE.md §4 is generated (64 genomes x 750
-genes x 370 aa, 25 % substitutions, seed 6401); `--faa FILE` runs a real file instead.
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself
+(torch.distributed.run on 127.0.0.1) BEFORE anything touches a GPU; under torchrun it is one of the ranks.
+With fewer than N GPUs visible (a one-GPU box) the ranks share device 0 and use gloo: a rehearsal, flagged
+`"rehearsal": true`, whose timings mean nothing.
 
-value = N*(N-1) ordered gene pairs / seconds per step  (the reference scores every
-row gene against all N columns).
-
-N > 1 (launched by torch.distributed.run, one rank per GPU): the genome tasks are sharded over the
-ranks (LPT on residues per genome, fixed before the dictionary build); the workload is the same set,
-so scaling is "strong".  Round-1 status: every rank builds the dictionary postings itself, range lists
-and scoring are per shard; collectives carry only scalar totals.
+Workload: BASELINE.json configs[2], the canonical 64-genome set — the stand-in of BASELINE.md §4 (64 genomes x 750
+genes x 370 aa, 25 % substitutions, seed 6401; the real Mycoplasma .faa cannot be fetched offline); `--faa FILE` runs a
+real file.  value = N*(N-1) ordered gene pairs / seconds per step (the reference scores every row
+gene against all N columns).  `scale_set` repeats the measurement on configs[3] (128 x 4000 x 300, the set BASELINE.json
+shards over 8 GPUs) at the same N, so that a 1/2/4/8 series has a workload large enough to show scaling
+(`--no-scale-set` skips it).
 
 Extra objects on the JSON line:
-  roofline     dominant kernel = K-join; achieved = algorithmic bytes of the join launch
-               (8 B per lookup + 20 B per emitted cell + 8 B per (gene, genome) maximum) divided by
-               its HIP-event duration measured inside the library on the launch stream.
-  cpu_baseline the reference's own library.cpp (oracle/_ref, kind "reference") — or the C
-               restatement (kind "port") when that build is absent — timed on this host's cores
-               on the same workload.
+  roofline             dominant kernel = K-join; achieved = algorithmic bytes of the join launch (8 B per lookup as the
+                       reference counts them + 20 B per emitted cell + 8 B per (gene, genome) maximum) / its HIP-event
+                       duration measured inside the library on the launch stream.  `traffic` comes from the committed
+                       rocprofv3 PMC profile of this workload (counters cannot be read by the run itself).
+  roofline_whole_path  the same for the whole step: SURVEY.md §8d's bytes_alg / step time.
+  cpu_baseline         the reference's own library.cpp (oracle/_ref, kind "reference") — or the C restatement
+                       (kind "port") when that build is absent — timed on this host's cores on the same workload.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import tempfile
 import time
@@ -42,6 +49,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+SCALE_SET = "synthetic_128x4000x300"
 
 
 def cpu_baseline(gs, k, pairs, max_threads):
@@ -71,6 +79,123 @@ def cpu_baseline(gs, k, pairs, max_threads):
             "lookups_per_s": o.total_cost / max(t2 - t1, 1e-9)}
 
 
+def launch_ranks(args) -> int:
+    """--gpus N without a launcher: start N rank processes (fresh children; this process never touches a GPU)."""
+    import torch
+    visible = torch.cuda.device_count()          # (counts devices without initialising the runtime)
+    env = dict(os.environ)
+    if visible < args.gpus:
+        if args.gpus > 6:
+            print(f"bench.py: {args.gpus} ranks asked for, {visible} GPU(s) visible, and a one-GPU rehearsal takes at most 6 ranks", file=sys.stderr)
+            return 2
+        env["PDL_BENCH_BACKEND"] = "gloo"
+        env["PDL_BENCH_ONE_DEVICE"] = "1"
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+class Runner:
+    """One rank's view of the job: device-resident inputs of a workload and the step function."""
+
+    def __init__(self, torch, dev, stream, n_gpus, rank, on_device_collectives):
+        self.torch, self.dev, self.stream = torch, dev, stream
+        self.n_gpus, self.rank, self.on_dev = n_gpus, rank, on_device_collectives
+
+    def load(self, gs, k):
+        torch = self.torch
+        from pandelos_amd.pangene_native import PangeneNative
+        self.gs, self.k = gs, k
+        pad = (-len(gs.residues)) % 16 + 16
+        self.t_res = torch.from_numpy(np.concatenate([gs.residues, np.zeros(pad, np.uint8)])).to(self.dev)
+        self.t_off = torch.from_numpy(gs.offsets.astype(np.int64)).to(self.dev)
+        self.t_gen = torch.from_numpy(gs.genome_of.astype(np.int32)).to(self.dev)
+        torch.cuda.synchronize()
+        # one context per rank for the whole run: every step redoes all the work, only allocations are reused
+        self.nat = PangeneNative.open(stream=self.stream)
+        self.dp = None
+        if self.n_gpus > 1:
+            from pandelos_amd.distributed import DistributedPangenes
+            self.dp = DistributedPangenes(self.nat, self.dev, self.on_dev)
+
+    def step(self):
+        gs = self.gs
+        if self.dp is None:
+            self.nat.preprocess_device(self.k, self.t_res.data_ptr(), self.t_off.data_ptr(), self.t_gen.data_ptr(), gs.genes, len(gs.residues))
+            self.nat.score_all()
+        else:
+            self.dp.preprocess(self.k, self.t_res, self.t_off, self.t_gen, gs.genes, len(gs.residues))
+            self.dp.score_all()
+
+    def sync(self):
+        if self.n_gpus > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def measure(self, steps, warmup, coll_dev):
+        from pandelos_amd import distributed as D
+        for _ in range(warmup):
+            self.step()
+        self.sync()
+        t0 = time.perf_counter()
+        join_ms, pre_ms, score_ms, xd, xc = [], [], [], [], []
+        for _ in range(steps):
+            self.step()
+            tm = self.nat.timings()
+            join_ms.append(tm["join_ms"] + tm["join_overflow_ms"])
+            pre_ms.append(tm["preprocess_total_ms"])
+            score_ms.append(tm["score_total_ms"])
+            if self.dp is not None:
+                xd.append(self.dp.exchange_s["dictionary"] * 1e3); xc.append(self.dp.exchange_s["cells"] * 1e3)
+        self.sync()
+        elapsed = D.all_reduce_max(time.perf_counter() - t0, device=coll_dev)
+        sec_per_step = elapsed / max(steps, 1)
+        gs, cost, tm = self.gs, self.nat.cost, self.nat.timings()
+        mean = lambda v: sum(v) / len(v) if v else 0.0
+        # algorithmic bytes of this rank's join launch (SURVEY.md §8d join terms; lookups as the reference counts them)
+        p_l, z_l, rows_l = tm["scored_lookups"], tm["emitted_cells"], tm["scored_rows"]
+        join_bytes = 8.0 * p_l + 20.0 * z_l + 8.0 * rows_l * gs.genomes
+        join_s = mean(join_ms) / 1e3
+        z_total, walked = D.all_reduce_sum([float(z_l), float(tm["walked_lookups"])], device=coll_dev)
+        p_total = float(cost.total_cost)
+        bytes_alg_total = (cost.residues + 16.0 * cost.kmer_occurrences + 16.0 * cost.dictionary_records +
+                           8.0 * p_total + 20.0 * z_total + 8.0 * gs.genes * gs.genomes)
+        pairs = float(gs.genes) * float(gs.genes - 1)
+        stage = {"preprocess": mean(pre_ms), "score": mean(score_ms), "hist": tm["hist_ms"], "rank": tm["rank_ms"],
+                 "sort_rank": tm["sort_rank_ms"], "dict": tm["dict_ms"], "sort_seq": tm["sort_seq_ms"], "ranges": tm["ranges_ms"],
+                 "join": tm["join_ms"], "join_overflow": tm["join_overflow_ms"], "order": tm["order_ms"],
+                 "tier2_rows": tm["tier2_rows"], "overflow_rows": tm["overflow_rows"]}
+        if self.dp is not None:
+            stage.update({"dist_begin": tm["dist_begin_ms"], "dist_finish": tm["dist_finish_ms"], "dist_score_begin": tm["dist_score_begin_ms"],
+                          "dist_score_finish": tm["dist_score_finish_ms"], "exchange_dictionary_wall": mean(xd), "exchange_cells_wall": mean(xc),
+                          "outbox_cells_rank0": tm["outbox_cells"]})
+        return {"pairs": pairs, "sec_per_step": sec_per_step, "cost": cost, "stage_ms": stage, "join_bytes": join_bytes, "join_s": join_s,
+                "bytes_alg_total": bytes_alg_total, "z_total": z_total, "p_total": p_total, "walked": walked}
+
+    def host_path(self, iters):
+        """SURVEY.md §8d wall time: host arrays -> dictionary -> scores -> every genome's Scores block on the host."""
+        gs = self.gs
+        best, times = None, []
+        for _ in range(iters + 1):
+            t0 = time.perf_counter()
+            self.nat.preprocess(self.k, gs.residues, gs.offsets, gs.genome_of)
+            cells = 0
+            for g in range(gs.genomes):
+                cells += int(self.nat.generate_scores_part(g).scoresCount)
+            times.append(time.perf_counter() - t0)
+        times = times[1:]                                   # first pass allocates the pinned mirror
+        return {"ms": 1e3 * sum(times) / len(times), "ms_min": 1e3 * min(times), "iterations": len(times), "cells": cells,
+                "through": "pdl_preprocess + pdl_compute_scores for every genome, via the Python binding (one extra copy per array)"}
+
+    def close(self):
+        self.nat.close()
+        del self.t_res, self.t_off, self.t_gen
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,13 +205,17 @@ def main():
     ap.add_argument("--faa", default=None, help="run a real .faa instead of the synthetic stand-in")
     ap.add_argument("--k", type=int, default=0, help="override k (default: calculate_k)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-scale-set", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=64)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
 
     import torch
     from pandelos_amd.calculate_k import calculate_k
     from pandelos_amd.pangene_idata import PangeneIData
-    from pandelos_amd.pangene_native import PangeneNative
     from pandelos_amd.synth import CONFIGS, GeneSet, make_gene_set
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -94,10 +223,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
     # PDL_BENCH_BACKEND=gloo + PDL_BENCH_ONE_DEVICE=1 rehearse the N > 1 flow on a one-GPU box (every rank on cuda:0,
-    # collectives on CPU tensors); the driver's runs use RCCL ("nccl"), one rank per GPU.
+    # exchanges staged through host tensors); the driver's runs use RCCL ("nccl"), one rank per GPU.
     backend = os.environ.get("PDL_BENCH_BACKEND", "nccl")
-    dev_index = 0 if os.environ.get("PDL_BENCH_ONE_DEVICE") == "1" else local_rank
-    dev = torch.device("cuda", dev_index)
+    rehearsal = os.environ.get("PDL_BENCH_ONE_DEVICE") == "1"
+    dev = torch.device("cuda", 0 if rehearsal else local_rank)
     torch.cuda.set_device(dev)
     if distributed:
         import torch.distributed as dist
@@ -107,6 +236,8 @@ def main():
             dist.init_process_group(backend)
     n_gpus = world if distributed else 1
     coll_dev = dev if backend == "nccl" else None      # where the scalar collectives live
+    stream = torch.cuda.current_stream().cuda_stream
+    run = Runner(torch, dev, stream, n_gpus, rank, backend == "nccl")
 
     # ---- workload -----------------------------------------------------------------------------------
     if args.faa:
@@ -122,68 +253,16 @@ def main():
                     f"{shape['mean_len']} aa, {int(shape['sub_rate'] * 100)}% substitutions, seed {shape['seed']}")
         data_kind = "synthetic"
     k = args.k or calculate_k(gs.residues)
-    n_genes, n_genomes = gs.genes, gs.genomes
-    pairs = float(n_genes) * float(n_genes - 1)
-
-    pad = (-len(gs.residues)) % 16 + 16
-    t_res = torch.from_numpy(np.concatenate([gs.residues, np.zeros(pad, np.uint8)])).to(dev)
-    t_off = torch.from_numpy(gs.offsets.astype(np.int64)).to(dev)
-    t_gen = torch.from_numpy(gs.genome_of.astype(np.int32)).to(dev)
-    stream = torch.cuda.current_stream().cuda_stream
-    torch.cuda.synchronize()
-
-    from pandelos_amd import distributed as D
-
-    # one context per rank for the whole run: every step redoes all the work, only allocations are reused.
-    # N > 1: genomes are dealt to ranks once (LPT on residues per genome); the shard is in force before the
-    # dictionary build, so a rank builds range lists for, and scores, only its own genes.
-    nat = PangeneNative.open(stream=stream)
-    if n_gpus > 1:
-        shard = D.shard_for_rank(gs.offsets, gs.genome_of, n_gpus, rank)
-        D.gather_genome_owner(shard, n_genomes, device=coll_dev)      # the shards must partition the genomes
-        nat.set_genome_shard(shard)
-
-    def one_step():
-        nat.preprocess_device(k, t_res.data_ptr(), t_off.data_ptr(), t_gen.data_ptr(), n_genes, len(gs.residues))
-        nat.score_all()
-        return nat
-
-    def sync():
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        one_step()
-    sync()
-    t0 = time.perf_counter()
-    join_ms, pre_ms, score_ms = [], [], []
-    for _ in range(args.steps):
-        one_step()
-        tm = nat.timings()
-        join_ms.append(tm["join_ms"] + tm["join_overflow_ms"])
-        pre_ms.append(tm["preprocess_total_ms"])
-        score_ms.append(tm["score_total_ms"])
-    sync()
-    elapsed = time.perf_counter() - t0
-    elapsed = D.all_reduce_max(elapsed, device=coll_dev)
-    sec_per_step = elapsed / max(args.steps, 1)
-
-    cost = nat.cost
-    tm = nat.timings()
-    # algorithmic bytes of this rank's join launch (SURVEY.md §8d join terms)
-    p_l, z_l, rows_l = tm["scored_lookups"], tm["emitted_cells"], tm["scored_rows"]
-    join_bytes = 8.0 * p_l + 20.0 * z_l + 8.0 * rows_l * n_genomes
-    join_s = (sum(join_ms) / len(join_ms)) / 1e3 if join_ms else 0.0
-    achieved = join_bytes / join_s / 1e9 if join_s > 0 else 0.0
-    z_total, p_total = D.all_reduce_sum([float(z_l), float(cost.total_cost)], device=coll_dev)
-    bytes_alg_total = (cost.residues + 16.0 * cost.kmer_occurrences + 16.0 * cost.dictionary_records +
-                       8.0 * p_total + 20.0 * z_total + 8.0 * n_genes * n_genomes)
+    run.load(gs, k)
+    m = run.measure(args.steps, args.warmup, coll_dev)
+    cost = m["cost"]
+    achieved = m["join_bytes"] / m["join_s"] / 1e9 if m["join_s"] > 0 else 0.0
+    whole = m["bytes_alg_total"] / m["sec_per_step"] / 1e9
 
     # HBM-side traffic of the join launch from the committed PMC profile of this workload (FETCH_SIZE / WRITE_SIZE
     # are collected in separate rocprofv3 --pmc passes, corrected as MI355X_MICROARCH.md prescribes; see
     # profiles/*_pmc_traffic_join.json).  null when no profile of this workload/sharding is on file.
-    traffic = None
+    traffic, traffic_src = None, None
     if n_gpus == 1 and not args.faa:
         for pf in sorted((ROOT / "profiles").glob("r*b_pmc_traffic_join.json"), reverse=True):
             try:
@@ -191,42 +270,71 @@ def main():
                 if prof.get("workload") == args.config:
                     traffic = sum(v.get("hbm_bytes_per_launch_corrected", 0.0) for kname, v in prof["kernels"].items()
                                   if "k_join" in kname)
+                    traffic_src = f"profiles/{pf.name}"
                     break
             except Exception:
                 pass
 
+    sharding = ("whole dataset on one GPU" if n_gpus == 1 else
+                f"{n_gpus} ranks: rank-interval dictionary build + all-gather of the runs, genomes dealt by lookups above the diagonal, "
+                "upper-triangle join + all-to-all of mirrored cells")
     out = {
         "metric": "scored gene-pairs/sec (whole node)",
-        "value": pairs / sec_per_step,
+        "value": m["pairs"] / m["sec_per_step"],
         "unit": "gene-pairs/s",
         "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": sec_per_step * 1e3,
+        "ms_per_step": m["sec_per_step"] * 1e3,
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "u32 accumulate + f32 finalize",
         "data": data_kind,
-        "config": {"workload": workload, "genes": n_genes, "genomes": n_genomes, "residues": int(cost.residues),
+        "config": {"workload": workload, "genes": gs.genes, "genomes": gs.genomes, "residues": int(cost.residues),
                    "k": int(k), "kmer_occurrences": int(cost.kmer_occurrences),
-                   "dictionary_records": int(cost.dictionary_records), "lookups": int(p_total),
-                   "emitted_cells": int(z_total), "sharding": f"genome tasks over {n_gpus} GPU(s) (LPT on residues); postings built on every rank, "
-                               "range lists and scoring per shard"},
-        "achieved_hbm_GBps_whole_path": bytes_alg_total / sec_per_step / 1e9,
-        "lookups_per_s": p_total / sec_per_step,
-        "stage_ms": {"preprocess": sum(pre_ms) / len(pre_ms), "score": sum(score_ms) / len(score_ms),
-                     "hist": tm["hist_ms"], "rank": tm["rank_ms"], "sort_rank": tm["sort_rank_ms"], "dict": tm["dict_ms"],
-                     "sort_seq": tm["sort_seq_ms"], "ranges": tm["ranges_ms"], "join": tm["join_ms"],
-                     "join_overflow": tm["join_overflow_ms"], "order": tm["order_ms"],
-                     "tier2_rows": tm["tier2_rows"], "overflow_rows": tm["overflow_rows"]},
+                   "dictionary_records": int(cost.dictionary_records), "lookups": int(m["p_total"]),
+                   "lookups_walked": int(m["walked"]), "emitted_cells": int(m["z_total"]),
+                   "cells_per_row": m["z_total"] / max(gs.genes, 1), "sharding": sharding},
+        "timed_region": "inputs and outputs resident in HBM (host_path = SURVEY §8d host-to-host wall time)",
+        "lookups_per_s": m["p_total"] / m["sec_per_step"],
+        "stage_ms": m["stage_ms"],
         "roofline": {"bound": "hbm", "kernel": "k_join_lds (+k_join_hbm)", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                     "bytes_per_launch": join_bytes, "launch_ms": join_s * 1e3},
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
+                     "bytes_per_launch": m["join_bytes"], "launch_ms": m["join_s"] * 1e3},
+        "roofline_whole_path": {"bound": "hbm", "achieved": whole, "peak": HBM_PEAK_GBPS * n_gpus, "unit": "GB/s",
+                                "frac": whole / (HBM_PEAK_GBPS * n_gpus), "bytes_alg": m["bytes_alg_total"],
+                                "formula": "1*R + 16*M + 16*U + 8*P + 20*Z + 8*N*G (SURVEY.md §8d)"},
     }
-    nat.close()
+    if rehearsal:
+        out["rehearsal"] = True
+    if n_gpus == 1 and not args.no_host_path:
+        hp = run.host_path(5)
+        hp["value"] = m["pairs"] / (hp["ms"] / 1e3)
+        hp["unit"] = "gene-pairs/s"
+        out["host_path"] = hp
+    run.close()
+
+    # ---- the set BASELINE.json shards over 8 GPUs, at this N ------------------------------------------------------
+    if not args.no_scale_set and not args.faa and args.config != SCALE_SET:
+        shape = CONFIGS[SCALE_SET]
+        gs2 = make_gene_set(**shape)
+        k2 = calculate_k(gs2.residues)
+        run.load(gs2, k2)
+        m2 = run.measure(max(2, min(args.steps, 5)), 1, coll_dev)
+        a2 = m2["join_bytes"] / m2["join_s"] / 1e9 if m2["join_s"] > 0 else 0.0
+        out["scale_set"] = {
+            "workload": f"{SCALE_SET}: synthetic 128 genomes x 4000 genes x 300 aa, 8% substitutions, seed {shape['seed']}",
+            "value": m2["pairs"] / m2["sec_per_step"], "unit": "gene-pairs/s", "n_gpus": n_gpus, "ms_per_step": m2["sec_per_step"] * 1e3,
+            "genes": gs2.genes, "k": int(k2), "lookups": int(m2["p_total"]), "lookups_walked": int(m2["walked"]),
+            "emitted_cells": int(m2["z_total"]), "stage_ms": m2["stage_ms"],
+            "roofline_join_frac": a2 / HBM_PEAK_GBPS,
+            "roofline_whole_path_frac": m2["bytes_alg_total"] / m2["sec_per_step"] / 1e9 / (HBM_PEAK_GBPS * n_gpus)}
+        run.close()
+        del gs2
+
     if rank == 0:
         if n_gpus == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(gs, k, pairs, args.cpu_threads)
+                out["cpu_baseline"] = cpu_baseline(gs, k, m["pairs"], args.cpu_threads)
             except Exception as e:  # the baseline must never take the measurement down
                 out["cpu_baseline"] = {"value": None, "unit": "gene-pairs/s", "cores": 0, "kind": "unavailable",
                                        "sample": f"failed: {e}"}

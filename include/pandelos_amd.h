@@ -178,10 +178,10 @@ PDL_API int pdl_set_option(pdl_ctx *, const char *name, int64_t value);
  *                               of the records).  Result: its run of the dictionary, pdl_dist_slice.
  *   -- caller: all-gather the record counts, then the runs themselves into ONE device array in rank order
  *      (the concatenation IS the dictionary in (rank, gene) order: no merge) --
- *   pdl_dist_preprocess_finish  adopts that array (must stay valid until the next preprocess), builds the rank-groups
- *                               (library.cpp:289-335), deals the genomes to ranks (longest-processing-time on each
- *                               genome's lookups above the diagonal, computed identically everywhere) and builds the
- *                               posting-range lists of this rank's genes.
+ *   pdl_dist_preprocess_finish  adopts that array (must stay valid until the next preprocess), deals the genomes to ranks
+ *                               (longest-processing-time on each genome's lookups above the diagonal: identical input,
+ *                               identical deal on every rank) and builds the rank-groups and posting-range lists
+ *                               (library.cpp:289-335) of this rank's genes.
  *   pdl_dist_score_begin        scores this rank's rows against the genes ABOVE them only; a cell whose column belongs to
  *                               another rank's genome is also that rank's cell (c, r) (same sums, perc/tr_perc swapped):
  *                               such cells are listed per destination rank, pdl_dist_outbox.
@@ -193,6 +193,9 @@ typedef struct {
     const void *d_postings;   /* device, records x 8 bytes {gene u32, count u32 | group-head flag in bit 31} */
     uint64_t records;         /* unique (rank, gene) records of this rank's interval */
     uint64_t kmers;           /* k-mer occurrences of this rank's interval */
+    const uint64_t *genome_weights; /* host, [genomes]: every genome's lookups above the diagonal inside this run; summed over
+                                 the ranks they are the weights of the genome deal; valid until the next call on this context */
+    uint32_t genomes;
 } pdl_dist_slice;
 
 typedef struct { float score, perc, tr_perc; uint32_t row, column, first_group; } pdl_dist_cell;   /* cell (row, column) as its row's rank computed it */
@@ -206,7 +209,11 @@ typedef struct {
 PDL_API int pdl_dist_preprocess_begin(pdl_ctx *, const uint8_t *d_residues, const uint64_t *d_offsets, const uint32_t *d_genome_of,
                                       uint32_t n_sequences, uint64_t n_residues, int kvalue, uint32_t world, uint32_t rank,
                                       pdl_dist_slice *out);
-PDL_API int pdl_dist_preprocess_finish(pdl_ctx *, void *d_postings_all, uint64_t total_records, pdl_cost *out_cost /* may be NULL */);
+/* genome_weights: [G], the element-wise sum of every rank's pdl_dist_slice.genome_weights (one small all-reduce beside
+ * the record counts) — the SAME vector on every rank; NULL: the library takes one more pass over the gathered
+ * dictionary and computes them itself. */
+PDL_API int pdl_dist_preprocess_finish(pdl_ctx *, void *d_postings_all, uint64_t total_records, const uint64_t *genome_weights /* may be NULL */,
+                                       pdl_cost *out_cost /* may be NULL */);
 PDL_API int pdl_dist_genome_owner(const pdl_ctx *, uint32_t *out_owner /* [G] */);
 PDL_API int pdl_dist_score_begin(pdl_ctx *, pdl_dist_outbox *out);
 PDL_API int pdl_dist_score_finish(pdl_ctx *, const pdl_dist_cell *d_inbox, uint64_t n_inbox);

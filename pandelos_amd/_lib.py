@@ -62,7 +62,8 @@ class PdlTimings(C.Structure):
 
 
 class PdlDistSlice(C.Structure):
-    _fields_ = [("d_postings", C.c_void_p), ("records", C.c_uint64), ("kmers", C.c_uint64)]
+    _fields_ = [("d_postings", C.c_void_p), ("records", C.c_uint64), ("kmers", C.c_uint64),
+                ("genome_weights", C.POINTER(C.c_uint64)), ("genomes", C.c_uint32)]
 
 
 class PdlDistOutbox(C.Structure):
@@ -119,7 +120,7 @@ def load():
     lib.pdl_set_option.argtypes = [vp, C.c_char_p, C.c_int64]; lib.pdl_set_option.restype = i32
     lib.pdl_dist_preprocess_begin.argtypes = [vp, vp, vp, vp, u32, u64, i32, u32, u32, C.POINTER(PdlDistSlice)]
     lib.pdl_dist_preprocess_begin.restype = i32
-    lib.pdl_dist_preprocess_finish.argtypes = [vp, vp, u64, C.POINTER(PdlCost)]; lib.pdl_dist_preprocess_finish.restype = i32
+    lib.pdl_dist_preprocess_finish.argtypes = [vp, vp, u64, vp, C.POINTER(PdlCost)]; lib.pdl_dist_preprocess_finish.restype = i32
     lib.pdl_dist_genome_owner.argtypes = [vp, vp]; lib.pdl_dist_genome_owner.restype = i32
     lib.pdl_dist_score_begin.argtypes = [vp, C.POINTER(PdlDistOutbox)]; lib.pdl_dist_score_begin.restype = i32
     lib.pdl_dist_score_finish.argtypes = [vp, vp, u64]; lib.pdl_dist_score_finish.restype = i32

@@ -432,11 +432,12 @@ int pdl_dist_preprocess_begin(pdl_ctx *c, const uint8_t *d_residues, const uint6
     c->shard.clear(); c->shard_set = false; c->dict_shard.clear();
     pdl_run_dist_begin(c, k);
     out->d_postings = c->post.p; out->records = c->U_slice; out->kmers = c->M_slice;
+    out->genome_weights = c->h_run_weights.data(); out->genomes = c->G;
     return PDL_OK;
     PDL_GUARD_END(c)
 }
 
-int pdl_dist_preprocess_finish(pdl_ctx *c, void *d_postings_all, uint64_t total_records, pdl_cost *out_cost) {
+int pdl_dist_preprocess_finish(pdl_ctx *c, void *d_postings_all, uint64_t total_records, const uint64_t *genome_weights, pdl_cost *out_cost) {
     if (!c) return PDL_ERR_ARGUMENT;
     std::lock_guard<std::mutex> lk(c->mu);
     PDL_GUARD_BEGIN
@@ -446,7 +447,7 @@ int pdl_dist_preprocess_finish(pdl_ctx *c, void *d_postings_all, uint64_t total_
                                              (unsigned long long) total_records, (unsigned long long) c->U_slice);
     PDL_HIP(hipSetDevice(c->device));
     c->post_ext = static_cast<uint2 *>(d_postings_all);
-    pdl_run_dist_finish(c, total_records);
+    pdl_run_dist_finish(c, total_records, genome_weights);
     c->preprocessed = true;
     fill_cost(c, out_cost);
     return PDL_OK;
@@ -518,7 +519,7 @@ int pdl_get_dictionary(pdl_ctx *c, uint64_t *ranks, uint32_t *seqs, uint32_t *co
         if (ranks) ranks[u] = c->key64 ? reinterpret_cast<uint64_t *>(keys.data())[recpos[u]]
                                        : (uint64_t) reinterpret_cast<uint32_t *>(keys.data())[recpos[u]];
         if (seqs) seqs[u] = post[u].x;
-        if (counts) counts[u] = post[u].y;
+        if (counts) counts[u] = post[u].y & 0x7fffffffu;       // (complexity-only mode leaves the group-head bit in place)
     }
     return PDL_OK;
     PDL_GUARD_END(c)

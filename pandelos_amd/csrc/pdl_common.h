@@ -121,9 +121,7 @@ struct pdl_ctx {
     DevBuf keys_a, keys_b, vals_a, vals_b, sort_tmp;
     bool key64 = false;
     DevBuf recpos;        // u32 [U+1] position of each record's first occurrence in the sorted stream
-    DevBuf post;          // uint2 [U] {seq, count}  — the dictionary postings, rank-group major
-    DevBuf gid;           // u32 [U] group index of each record
-    DevBuf goff;          // u32 [NG+1] first record of each group
+    DevBuf post;          // uint2 [U] {seq, count}  — the dictionary postings, rank-group major (bit 31 of count: opens a rank-group, until K-ranges removes it)
     DevBuf ranges;        // uint4 [U'] {group start, group length, own count, 0}, gene major
     DevBuf seq_off;       // u32 [N+1] range list of each gene
     bool upper_only = false;  // ranges hold only the columns above the row: the join mirrors every cell
@@ -184,6 +182,7 @@ struct pdl_ctx {
     uint64_t U_slice = 0, M_slice = 0;
     std::vector<uint32_t> h_owner;            // [G] rank of every genome
     std::vector<uint64_t> h_upper_cost;       // [G] lookups above the diagonal per genome (what a rank's join walks)
+    std::vector<uint64_t> h_run_weights;      // [G] the same inside this rank's run of the dictionary (summed over ranks: the deal's weights)
     DevBuf owner_of_genome;                   // u32 [G]
     DevBuf local_genome;                      // u32 [G] index in the shard, 0xffffffff for other ranks' genomes
     DevBuf outbox;                            // pdl_dist_cell [remote mirrored cells], grouped by destination rank
@@ -230,7 +229,7 @@ struct PinRead {
 // stage entry points (pdl_dict.hip / pdl_join.hip)
 void pdl_run_preprocess(pdl_ctx *c, int kvalue, bool only_complexity);
 void pdl_run_dist_begin(pdl_ctx *c, int kvalue);
-void pdl_run_dist_finish(pdl_ctx *c, uint64_t total_records);
+void pdl_run_dist_finish(pdl_ctx *c, uint64_t total_records, const uint64_t *genome_weights);
 void pdl_run_score_all(pdl_ctx *c);
 void pdl_run_dist_score_begin(pdl_ctx *c);
 void pdl_run_dist_score_finish(pdl_ctx *c, const pdl_dist_cell *d_inbox, uint64_t n_inbox);

@@ -7,8 +7,8 @@
 //   K-rank    k_rank / k_rank_hash   per-gene k-mer ranks                    library.cpp:75-86,134-150
 //   K-sort    pdl_sort_pairs      stable LSD radix sort by rank              library.cpp:172-187,270-278
 //   K-rle     RecHead/RecScatter scan (records built in the apply)   dedup -> (rank,gene,count)   library.cpp:280-287
-//   K-groups  GroupHead scan, k_group_offsets, k_record_costs (+ the last-record fold)  library.cpp:297-335
-//   K-ranges  SharedScatter compaction, sort by gene, k_gather_ranges (+ per-gene cost), k_seq_offsets   library.cpp:312-327
+//   K-groups  k_fold_last_record, k_group_tiles (group extents from head bits, per tile)  library.cpp:297-335
+//   K-ranges  k_group_tiles (range tuples), sort by gene, k_gather_ranges (+ per-gene cost), k_seq_offsets   library.cpp:312-327
 //   K-cost    k_genome_cost       per-genome and total lookups               library.cpp:337-350,535-538
 //
 // HBM layout after this stage (what the join reads):
@@ -153,9 +153,9 @@ __device__ __forceinline__ uint64_t load_residues8(const uint8_t *__restrict__ r
 constexpr uint32_t DIST_BIN_BITS = 12, DIST_BINS = 1u << DIST_BIN_BITS;
 
 // MODE 0: keys[q] = rank, vals[q] = gene for every slot q of the k-mer stream (one workgroup per tile).
-// MODE 1: only counts the ranks by their top bits into bins[DIST_BINS] (persistent workgroups over the tiles, LDS
-//         histogram, one global atomic per non-empty bin and workgroup): the k-mer count of every rank interval, from
-//         which pdl_dist_preprocess_begin derives the same cuts on every GPU.
+// MODE 1: the same, and counts the ranks by their top bits into bins[DIST_BINS] (persistent workgroups over the tiles,
+//         LDS histogram, one global atomic per non-empty bin and workgroup): the k-mer count of every rank interval,
+//         from which pdl_dist_preprocess_begin derives the same cuts on every GPU.
 template <class KeyT, int MODE>
 __global__ __launch_bounds__(RANK_THREADS) void k_rank(const uint8_t *__restrict__ res, const uint64_t *__restrict__ off,
                                                        const uint64_t *__restrict__ kmer_off, uint32_t n_seq, uint64_t m, uint64_t n_res,
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(RANK_THREADS) void k_rank(const uint8_t *__restrict
         const uint64_t q = q0 + (uint64_t) j * RANK_THREADS + threadIdx.x;
         if (q < m) {
             if constexpr (MODE == 1) atomicAdd(&s_bins[(uint32_t) (r[j] >> bin_shift)], 1u);
-            else { keys[q] = r[j]; vals[q] = sq[j]; }
+            keys[q] = r[j]; vals[q] = sq[j];
         }
     }
   }
@@ -256,7 +256,7 @@ __device__ __forceinline__ uint64_t update_rank_hash_dev(uint64_t current, uint6
     return r;
 }
 
-// MODE 1 counts the ranks by their top DIST_BIN_BITS bits instead of writing them (see k_rank).
+// MODE 1 also counts the ranks by their top DIST_BIN_BITS bits (see k_rank).
 template <int MODE>
 __global__ __launch_bounds__(256) void k_rank_hash(const uint8_t *__restrict__ res, const uint64_t *__restrict__ off,
                                                    const uint64_t *__restrict__ kmer_off, uint32_t n_seq, RankParams rp,
@@ -275,10 +275,12 @@ __global__ __launch_bounds__(256) void k_rank_hash(const uint8_t *__restrict__ r
     uint64_t rank = 0;
     const uint64_t v0 = s_rv[0];
     for (uint32_t i = 0; i < k; i++) rank = update_rank_hash_dev(rank, s_rv[p[i]], v0, rp.last_multiplier, rp.base);
-    if constexpr (MODE == 1) atomicAdd(&bins[rank >> (64 - DIST_BIN_BITS)], 1u); else { keys[q] = rank; vals[q] = s; q++; }
+    if constexpr (MODE == 1) atomicAdd(&bins[rank >> (64 - DIST_BIN_BITS)], 1u);
+    keys[q] = rank; vals[q] = s; q++;
     for (uint64_t i = k; i < len; i++) {
         rank = update_rank_hash_dev(rank, s_rv[p[i]], s_rv[p[i - k]], rp.last_multiplier, rp.base);
-        if constexpr (MODE == 1) atomicAdd(&bins[rank >> (64 - DIST_BIN_BITS)], 1u); else { keys[q] = rank; vals[q] = s; q++; }
+        if constexpr (MODE == 1) atomicAdd(&bins[rank >> (64 - DIST_BIN_BITS)], 1u);
+        keys[q] = rank; vals[q] = s; q++;
     }
 }
 
@@ -296,13 +298,12 @@ template <class KeyT> struct RecHead {
         return (uint32_t) (q == 0) | (uint32_t) (k0 != k1) | (uint32_t) (v0 != v1);
     }
 };
-// The apply side also builds the record: post[u] = {gene, run length}, ghead[u] = 1 when record u opens a rank-group
+// The apply side also builds the record: post[u] = {gene, run length | HEAD_BIT when record u opens a rank-group}
 // (its rank differs from the element just before it, which belongs to the previous record).  Runs are short (a k-mer
 // repeated inside one gene), so the head walks its own run.
 template <class KeyT> struct RecScatter {
     const KeyT *keys; const uint32_t *vals; uint64_t m;
-    uint32_t *recpos; uint2 *post; uint8_t *ghead;
-    uint32_t pack_head;     // 1: the head flag also rides in bit 31 of the count (the form a rank's run travels in, pdl_dist_slice)
+    uint32_t *recpos; uint2 *post;
     struct Loaded { uint32_t val, run; uint8_t head; };
     __device__ Loaded load(uint64_t q, uint32_t) const {    // straight-line for the common run of one; the rare longer run loops
         const uint64_t qp = q ? q - 1 : 0, qn = q + 1 < m ? q + 1 : q;
@@ -319,45 +320,10 @@ template <class KeyT> struct RecScatter {
     __device__ void store(uint64_t q, uint32_t f, uint32_t prefix, const Loaded &v) const {
         if (!f) return;
         recpos[prefix] = (uint32_t) q;
-        post[prefix] = make_uint2(v.val, v.run | (((uint32_t) v.head & pack_head) << 31));
-        ghead[prefix] = v.head;
+        post[prefix] = make_uint2(v.val, v.run | ((uint32_t) v.head << 31));
     }
 };
 
-// The reference's scan (library.cpp:300-306) closes the current group at the LAST record with end = i + 1 whatever
-// its rank, i.e. the last record never opens a group: when it is the only record of the largest rank it is folded
-// into the preceding group (and moved to its gene-order place by k_fold_last_record).
-struct GroupHeadFlag {
-    const uint8_t *ghead; const uint64_t *d_u;       // *d_u = U (the host has not read it back)
-    __device__ uint32_t operator()(uint64_t u) const { const uint64_t u_count = *d_u; return (u_count >= 2 && u == u_count - 1) ? 0u : ghead[u]; }
-};
-struct GroupScatter {
-    uint32_t *gid; uint32_t *goff; const uint64_t *d_u;
-    __device__ void operator()(uint64_t u, uint32_t f, uint32_t prefix) const {
-        gid[u] = prefix + f - 1;           // inclusive count - 1
-        if (f) goff[prefix] = (uint32_t) u;
-        const uint64_t u_count = *d_u;
-        if (u == u_count - 1) goff[prefix + f] = (uint32_t) u_count;      // closes the offsets: goff[number of groups] = U
-    }
-};
-// The same scan over an all-gathered dictionary (multi-GPU): the head flags arrive in bit 31 of the counts and are
-// taken out again by the apply step (every workgroup has evaluated its tile's flags before its first store).
-struct GroupHeadFlagPacked {
-    const uint2 *post; const uint64_t *d_u;
-    __device__ uint32_t operator()(uint64_t u) const { const uint64_t u_count = *d_u; return (u_count >= 2 && u == u_count - 1) ? 0u : post[u].y >> 31; }
-};
-struct GroupScatterStrip {
-    uint32_t *gid; uint32_t *goff; const uint64_t *d_u; uint2 *post;
-    struct Loaded { uint32_t cnt; };
-    __device__ Loaded load(uint64_t u, uint32_t) const { return Loaded{post[u].y}; }
-    __device__ void store(uint64_t u, uint32_t f, uint32_t prefix, const Loaded &v) const {
-        gid[u] = prefix + f - 1;
-        if (f) goff[prefix] = (uint32_t) u;
-        const uint64_t u_count = *d_u;
-        if (u == u_count - 1) goff[prefix + f] = (uint32_t) u_count;
-        if (v.cnt >> 31) post[u].y = v.cnt & 0x7fffffffu;
-    }
-};
 // Interval selection of the multi-GPU build: the k-mers whose rank falls into this GPU's bins, in stream order.
 template <class KeyT> struct SelFlag {
     const KeyT *keys; uint32_t shift, b_lo, b_hi;
@@ -370,30 +336,81 @@ template <class KeyT> struct SelApply {
     __device__ void store(uint64_t, uint32_t f, uint32_t prefix, const Loaded &v) const { if (f) { keys_out[prefix] = v.key; vals_out[prefix] = v.val; } }
 };
 
-// The reference re-sorts every shared group by gene (library.cpp:312-315).  After the stable sort all groups
-// already are in gene order except the last one when the globally last record was folded into it (:300-306):
-// move that record to its place (insertion into a sorted run).  One workgroup; recpos moves along so that
-// (rank via recpos, gene, count) stay one record.  The join's "columns above the row" trick relies on this order.
-__global__ __launch_bounds__(1024) void k_fold_last_record(uint2 *__restrict__ post, uint32_t *__restrict__ recpos,
-                                                           const uint32_t *__restrict__ goff, const uint64_t *d_ng, const uint64_t *d_u) {
-    __shared__ uint32_t s_p;
+// ------------------------------------------------------------------------------------------------
+// K-groups + K-ranges, fused (library.cpp:289-335).  The dictionary arrives as postings {gene, count} in (rank, gene)
+// order with "opens a rank-group" in bit 31 of the count (set by K-rle; it is also the form the runs of a multi-GPU
+// build travel in).  A group is the records from one head to the next; nothing is materialised about groups: every
+// tile of 2048 records rebuilds the extents it needs from the head bits (a 64-bit ballot per wave and round, prev/next
+// head by bit scans), looks beyond its borders only for the groups that cross them, and emits — for the records that
+// get a posting range — the 16-byte tuple {first posting, postings, own count, group size} and the gene as sort key:
+//
+//   k_fold_last_record   the reference's scan closes the current group at the LAST record whatever its rank
+//                        (library.cpp:300-306): a last record that opens a group of its own is folded into the preceding
+//                        group, moved to its gene-order place there (:312-315) and the head bits are put right, so that
+//                        from here on the bits alone say what the reference's groups are
+//   k_group_tiles<COUNT> ranges per tile (+ first/last head of every tile; + counters U', shared groups; + per-genome
+//                        lookups; + per-gene costs in complexity-only mode)
+//   (scan of the tile counts)
+//   k_group_tiles<WRITE> tuples and keys at tile offset + position inside the tile (record order), the group size of a
+//                        group's last member added to its gene's cost (it has no range of its own), head bits removed
+//
+// Two passes over the postings replace the group scan (gid/goff), the shared-record compaction and the counter pass
+// of the first version, i.e. about six passes over record-sized arrays.  The WRITE pass removes the head bits of its
+// own tile only and asks the per-tile head positions of the COUNT pass about its neighbours, so no tile ever reads
+// a bit another one may already have removed.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t HEAD_BIT = 0x80000000u;
+constexpr int GT_THREADS = 256, GT_ITEMS = 8, GT_TILE = GT_THREADS * GT_ITEMS, GT_WORDS = GT_TILE / PDL_WAVE;      // 2048 records, 32 mask words
+constexpr uint32_t GT_NONE = 0xffffffffu;
+constexpr uint32_t COST_LDS_GENOMES = 4096;
+
+// last head at or before pos (record 0 always is one); one wave, 64 records per step
+__device__ __forceinline__ uint32_t find_head_back(const uint2 *post, uint32_t pos, uint32_t lane) {
+    for (;;) {
+        const uint32_t base = pos + 1 >= PDL_WAVE ? pos + 1 - PDL_WAVE : 0;
+        const uint32_t idx = base + lane;
+        const bool f = idx <= pos && ((post[idx <= pos ? idx : pos].y >> 31) || idx == 0);
+        const unsigned long long m = __ballot(f);
+        if (m) return base + 63u - (uint32_t) __clzll((long long) m);
+        pos = base - 1;                                   // (base > 0 here: index 0 always answers)
+    }
+}
+// first head at or after pos, n when there is none
+__device__ __forceinline__ uint32_t find_head_fwd(const uint2 *post, uint32_t pos, uint32_t n, uint32_t lane) {
+    for (uint32_t base = pos; base < n; base += PDL_WAVE) {
+        const uint32_t idx = base + lane;
+        const bool f = idx < n && (post[idx < n ? idx : n - 1].y >> 31);
+        const unsigned long long m = __ballot(f);
+        if (m) return base + (uint32_t) __ffsll((long long) m) - 1u;
+    }
+    return n;
+}
+
+// One workgroup.  recpos (position of each record's first occurrence in the sorted stream, for pdl_get_dictionary) moves
+// along when present.
+__global__ __launch_bounds__(1024) void k_fold_last_record(uint2 *__restrict__ post, uint32_t *__restrict__ recpos, const uint64_t *d_u) {
+    __shared__ uint32_t s_gs, s_p;
     const uint32_t u_count = (uint32_t) *d_u;
     if (u_count < 2) return;
-    const uint32_t gs = goff[*d_ng - 1];
     const uint32_t lastp = u_count - 1;
-    const uint2 last = post[lastp];
-    const uint32_t last_rp = recpos ? recpos[lastp] : 0u;      // (no recpos over an all-gathered dictionary)
-    if (threadIdx.x == 0) {
-        uint32_t lo = gs, hi = lastp;                    // first index in [gs, lastp) whose gene is above the last record's
-        while (lo < hi) {
-            const uint32_t mid = lo + ((hi - lo) >> 1);
-            if (post[mid].x <= last.x) lo = mid + 1; else hi = mid;
+    uint2 last = post[lastp];
+    if (!(last.y >> 31)) return;                         // (uniform) the last record belongs to its group anyway, in gene order
+    last.y &= ~HEAD_BIT;                                 // it never opens a group (library.cpp:300-306)
+    const uint32_t last_rp = recpos ? recpos[lastp] : 0u;
+    if (threadIdx.x < PDL_WAVE) {
+        const uint32_t gs = find_head_back(post, lastp - 1, threadIdx.x);       // the group it joins
+        if (threadIdx.x == 0) {
+            uint32_t lo = gs, hi = lastp;                // first index in [gs, lastp) whose gene is above the last record's
+            while (lo < hi) {
+                const uint32_t mid = lo + ((hi - lo) >> 1);
+                if (post[mid].x <= last.x) lo = mid + 1; else hi = mid;
+            }
+            s_gs = gs; s_p = lo;
         }
-        s_p = lo;
     }
     __syncthreads();
-    const uint32_t p = s_p;
-    if (p == lastp) return;                              // already in place (uniform)
+    const uint32_t p = s_p, gs = s_gs;
+    if (p == lastp) { if (threadIdx.x == 0) post[lastp] = last; return; }       // already in place (uniform)
     for (uint32_t hi = lastp; hi > p; hi = hi > 1024 ? hi - 1024 : 0) {
         const bool live = hi >= 1 + threadIdx.x && hi - 1 - threadIdx.x >= p;
         const uint32_t i = hi - 1 - threadIdx.x;
@@ -405,125 +422,194 @@ __global__ __launch_bounds__(1024) void k_fold_last_record(uint2 *__restrict__ p
         __syncthreads();
         if (hi <= 1024) break;
     }
-    if (threadIdx.x == 0) { post[p] = last; if (recpos) recpos[p] = last_rp; }
+    if (threadIdx.x == 0) {
+        if (p == gs) { last.y |= HEAD_BIT; post[gs + 1].y &= ~HEAD_BIT; }       // the moved record is the group's smallest gene: it is the head now
+        post[p] = last;
+        if (recpos) recpos[p] = last_rp;
+    }
 }
 
-// Counters over the whole dictionary, one grid-stride pass: records in shared groups (U'), shared groups, and — multi-GPU —
-// every genome's lookups as the reference counts them ("Genome g cost", library.cpp:327,535-538: each record of a shared
-// group adds the group size) and above the diagonal (the postings after the record: what the symmetric join walks).
-// Sums are kept per lane, reduced per wave and workgroup; genome sums go through an LDS table (G <= COST_LDS_GENOMES,
-// global atomics beyond that).  out[0] += U', out[1] += groups.
-constexpr uint32_t COST_LDS_GENOMES = 4096;
-template <bool GENOMES>
-__global__ __launch_bounds__(256) void k_dictionary_counters(const uint2 *__restrict__ post, const uint32_t *__restrict__ gid,
-                                                             const uint32_t *__restrict__ goff, const uint64_t *d_u,
-                                                             const uint32_t *__restrict__ genome_of, uint32_t n_genomes,
-                                                             unsigned long long *__restrict__ out,
-                                                             unsigned long long *__restrict__ g_full, unsigned long long *__restrict__ g_upper) {
+struct GroupTileArgs {
+    uint2 *post;
+    uint64_t n_bound; const uint64_t *d_n;      // record count: on the device (at most n_bound) or n_bound itself
+    const uint8_t *in_shard;                    // MODE 0, 2: the genes that get range lists
+    uint32_t *tile_sums;                        // [tiles] ranges per tile; exclusive-scanned between the passes
+    uint32_t *th_first, *th_last;               // [tiles] first / last head of a tile (GT_NONE: none), COUNT -> WRITE
+    uint32_t *key2; uint4 *tuples;              // WRITE
+    unsigned long long *cost;                   // per-gene total_visited (library.cpp:327): last members (WRITE), all shared records (COUNT, RECORD_COSTS)
+    unsigned long long *counters;               // COUNT: [0] += records in groups >= 2, [1] += such groups
+    const uint32_t *genome_of; uint32_t n_genomes;
+    unsigned long long *g_full, *g_upper;       // COUNT, GENOMES: per genome, lookups as the reference counts them / above the diagonal
+};
+
+// MODE 0: whole groups for the genes of a shard | 1: the postings above the record, every gene | 2: those, for the genes
+// of a shard | 3: no ranges (counters / costs only).  PASS 0 = COUNT, 1 = WRITE.
+template <int PASS, int MODE, bool GENOMES, bool RECORD_COSTS>
+__global__ __launch_bounds__(GT_THREADS) void k_group_tiles(GroupTileArgs a) {
+    __shared__ unsigned long long s_mask[GT_WORDS];
+    __shared__ uint32_t s_prevw[GT_WORDS], s_nextw[GT_WORDS], s_cnt[GT_WORDS];
+    __shared__ uint32_t s_before, s_after, s_red[2];
     __shared__ unsigned long long s_full[GENOMES ? COST_LDS_GENOMES : 1], s_upper[GENOMES ? COST_LDS_GENOMES : 1];
-    __shared__ uint32_t s_cnt[2];
-    const bool lds_table = GENOMES && n_genomes <= COST_LDS_GENOMES;
-    if constexpr (GENOMES) { if (lds_table) for (uint32_t i = threadIdx.x; i < n_genomes; i += 256) { s_full[i] = 0; s_upper[i] = 0; } }
-    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t u_count = (uint32_t) *d_u;
+    const uint32_t tid = threadIdx.x, lane = tid & (PDL_WAVE - 1), wave = tid / PDL_WAVE;
+    const uint32_t n = (uint32_t) scan_count(a.n_bound, a.d_n);
+    const uint32_t tiles = (n + GT_TILE - 1) / GT_TILE, tiles_bound = (uint32_t) ((a.n_bound + GT_TILE - 1) / GT_TILE);
+    const bool lds_table = GENOMES && a.n_genomes <= COST_LDS_GENOMES;
+    if constexpr (GENOMES) { if (lds_table) for (uint32_t i = tid; i < a.n_genomes; i += GT_THREADS) { s_full[i] = 0; s_upper[i] = 0; } }
     uint32_t n_rec = 0, n_grp = 0;
-    for (uint64_t u0 = (uint64_t) blockIdx.x * 256; u0 < u_count; u0 += (uint64_t) gridDim.x * 256) {
-        const uint32_t u = (uint32_t) u0 + threadIdx.x;
-        if (u >= u_count) continue;
-        const uint32_t g = gid[u];
-        const uint32_t gs = goff[g], ge = goff[g + 1];
-        if (ge - gs < 2) continue;
-        n_rec++;
-        n_grp += u == gs;
-        if constexpr (GENOMES) {
-            const uint32_t gen = genome_of[post[u].x];
-            const unsigned long long full = ge - gs, upper = ge - u - 1;
-            if (lds_table) { atomicAdd(&s_full[gen], full); if (upper) atomicAdd(&s_upper[gen], upper); }
-            else { atomicAdd(&g_full[gen], full); if (upper) atomicAdd(&g_upper[gen], upper); }
+    for (uint32_t tile = blockIdx.x; tile < tiles_bound; tile += gridDim.x) {
+        if (tile >= tiles) {                             // (uniform) beyond the records: the scan over tiles_bound entries reads zeros
+            if (PASS == 0 && tid == 0) { a.tile_sums[tile] = 0; a.th_first[tile] = GT_NONE; a.th_last[tile] = GT_NONE; }
+            continue;
         }
-    }
+        __syncthreads();                                 // the LDS words of the previous tile are done with
+        const uint32_t t0 = tile * GT_TILE;
+        uint2 po[GT_ITEMS];
 #pragma unroll
-    for (int d = PDL_WAVE / 2; d > 0; d >>= 1) { n_rec += __shfl_xor(n_rec, d, PDL_WAVE); n_grp += __shfl_xor(n_grp, d, PDL_WAVE); }
-    if ((threadIdx.x & (PDL_WAVE - 1)) == 0) { atomicAdd(&s_cnt[0], n_rec); atomicAdd(&s_cnt[1], n_grp); }
-    __syncthreads();
-    if (threadIdx.x < 2 && s_cnt[threadIdx.x]) atomicAdd(&out[threadIdx.x], (unsigned long long) s_cnt[threadIdx.x]);
-    if constexpr (GENOMES) {
-        if (lds_table) for (uint32_t i = threadIdx.x; i < n_genomes; i += 256) {
-            if (s_full[i]) atomicAdd(&g_full[i], s_full[i]);
-            if (s_upper[i]) atomicAdd(&g_upper[i], s_upper[i]);
+        for (int j = 0; j < GT_ITEMS; j++) {             // all loads first, branch-free
+            const uint32_t u = t0 + j * GT_THREADS + tid;
+            po[j] = a.post[u < n ? u : n - 1];
+        }
+#pragma unroll
+        for (int j = 0; j < GT_ITEMS; j++) {
+            const uint32_t u = t0 + j * GT_THREADS + tid;
+            const unsigned long long m = __ballot(u < n && (po[j].y >> 31));
+            if (lane == 0) s_mask[j * (GT_THREADS / PDL_WAVE) + wave] = m;
+        }
+        __syncthreads();
+        if (wave == 0) {                                 // per mask word: last head in the words before, first head in the words after
+            const unsigned long long mw = lane < GT_WORDS ? s_mask[lane] : 0ull;
+            const unsigned long long has = __ballot(mw != 0) & ((1ull << GT_WORDS) - 1ull);
+            if (lane < GT_WORDS) {
+                const unsigned long long lower = has & ((1ull << lane) - 1ull), upper = has & ~((2ull << lane) - 1ull);
+                uint32_t pv = GT_NONE, nx = GT_NONE;
+                if (lower) { const uint32_t w = 63u - (uint32_t) __clzll((long long) lower); pv = w * 64u + 63u - (uint32_t) __clzll((long long) s_mask[w]); }
+                if (upper) { const uint32_t w = (uint32_t) __ffsll((long long) upper) - 1u; nx = w * 64u + (uint32_t) __ffsll((long long) s_mask[w]) - 1u; }
+                s_prevw[lane] = pv; s_nextw[lane] = nx;
+            }
+            if (PASS == 0 && lane == 0) {
+                uint32_t fh = GT_NONE, lh = GT_NONE;
+                if (has) {
+                    const uint32_t wf = (uint32_t) __ffsll((long long) has) - 1u, wl = 63u - (uint32_t) __clzll((long long) has);
+                    fh = t0 + wf * 64u + (uint32_t) __ffsll((long long) s_mask[wf]) - 1u;
+                    lh = t0 + wl * 64u + 63u - (uint32_t) __clzll((long long) s_mask[wl]);
+                }
+                a.th_first[tile] = fh; a.th_last[tile] = lh;
+            }
+        } else if (wave == 1) {                          // head of the group that runs into this tile
+            uint32_t before = t0;
+            if (!(s_mask[0] & 1ull)) {
+                if constexpr (PASS == 0) before = find_head_back(a.post, t0 - 1, lane);      // (t0 > 0: record 0 is a head)
+                else {
+                    before = 0;
+                    for (uint32_t hi = tile; hi > 0;) {  // last head of the tiles before, 64 tiles per step
+                        const uint32_t base = hi >= PDL_WAVE ? hi - PDL_WAVE : 0, idx = base + lane;
+                        const uint32_t v = idx < hi ? a.th_last[idx] : GT_NONE;
+                        const unsigned long long m = __ballot(v != GT_NONE);
+                        if (m) { before = (uint32_t) __shfl((int) v, 63 - __clzll((long long) m), PDL_WAVE); break; }
+                        hi = base;
+                    }
+                }
+            }
+            if (lane == 0) s_before = before;
+        } else if (wave == 2) {                          // end of the group that runs out of this tile
+            const uint32_t t1 = min(t0 + GT_TILE, n);
+            uint32_t after = n;
+            if constexpr (PASS == 0) after = find_head_fwd(a.post, t1, n, lane);
+            else {
+                for (uint32_t lo = tile + 1; lo < tiles; lo += PDL_WAVE) {
+                    const uint32_t idx = lo + lane;
+                    const uint32_t v = idx < tiles ? a.th_first[idx] : GT_NONE;
+                    const unsigned long long m = __ballot(v != GT_NONE);
+                    if (m) { after = (uint32_t) __shfl((int) v, __ffsll((long long) m) - 1, PDL_WAVE); break; }
+                }
+            }
+            if (lane == 0) s_after = after;
+        }
+        __syncthreads();
+        const uint32_t before = s_before, after = s_after;
+        bool has_range[GT_ITEMS];
+        uint32_t gsv[GT_ITEMS], gev[GT_ITEMS];
+        unsigned long long rb[GT_ITEMS];
+#pragma unroll
+        for (int j = 0; j < GT_ITEMS; j++) {
+            const uint32_t li = j * GT_THREADS + tid, u = t0 + li;
+            const uint32_t w = li >> 6, b = li & 63u;
+            const unsigned long long m = s_mask[w];
+            const unsigned long long at_or_below = m & ((2ull << b) - 1ull), above = m & ~((2ull << b) - 1ull);
+            uint32_t gs, ge;
+            if (at_or_below) gs = t0 + w * 64u + 63u - (uint32_t) __clzll((long long) at_or_below);
+            else { const uint32_t pv = s_prevw[w]; gs = pv != GT_NONE ? t0 + pv : before; }
+            if (above) ge = t0 + w * 64u + (uint32_t) __ffsll((long long) above) - 1u;
+            else { const uint32_t nx = s_nextw[w]; ge = nx != GT_NONE ? t0 + nx : after; }
+            const bool live = u < n;
+            const bool shared = live && ge - gs >= 2;
+            bool r = shared;
+            if constexpr (MODE == 1 || MODE == 2) r = r && u + 1 < ge;           // the last member of a group has nothing above it
+            if constexpr (MODE == 0 || MODE == 2) r = r && a.in_shard[po[j].x];
+            if constexpr (MODE == 3) r = false;
+            has_range[j] = r; gsv[j] = gs; gev[j] = ge;
+            rb[j] = __ballot(r);
+            if constexpr (PASS == 0) {
+                n_rec += shared; n_grp += shared && u == gs;
+                if constexpr (RECORD_COSTS) { if (shared) atomicAdd(&a.cost[po[j].x], (unsigned long long) (ge - gs)); }
+                if constexpr (GENOMES) {
+                    if (shared) {
+                        const uint32_t gen = a.genome_of[po[j].x];
+                        const unsigned long long full = ge - gs, up = ge - u - 1;
+                        if (lds_table) { atomicAdd(&s_full[gen], full); if (up) atomicAdd(&s_upper[gen], up); }
+                        else { atomicAdd(&a.g_full[gen], full); if (up) atomicAdd(&a.g_upper[gen], up); }
+                    }
+                }
+            }
+            if (lane == 0) s_cnt[j * (GT_THREADS / PDL_WAVE) + wave] = (uint32_t) __popcll(rb[j]);
+        }
+        __syncthreads();
+        if (wave == 0) {                                 // exclusive prefix of the 32 (round, wave) counts = record order
+            const uint32_t v = lane < GT_WORDS ? s_cnt[lane] : 0u;
+            const uint32_t inc = wave_inclusive_scan_u32(v);
+            if (lane < GT_WORDS) s_cnt[lane] = inc - v;
+            if (PASS == 0 && lane == GT_WORDS - 1) a.tile_sums[tile] = inc;
+        }
+        if constexpr (PASS == 1) {
+            __syncthreads();
+            const uint32_t tile_prefix = a.tile_sums[tile];
+#pragma unroll
+            for (int j = 0; j < GT_ITEMS; j++) {
+                const uint32_t u = t0 + j * GT_THREADS + tid;
+                if (u >= n) continue;
+                const uint32_t cnt = po[j].y & ~HEAD_BIT;
+                if (po[j].y >> 31) a.post[u].y = cnt;                              // the bit has done its job
+                const uint32_t gs = gsv[j], ge = gev[j];
+                if (has_range[j]) {
+                    const uint32_t at = tile_prefix + s_cnt[j * (GT_THREADS / PDL_WAVE) + wave] + (uint32_t) __popcll(rb[j] & ((1ull << lane) - 1ull));
+                    const uint32_t start = MODE == 0 ? gs : u + 1;
+                    a.key2[at] = po[j].x;
+                    a.tuples[at] = make_uint4(start, ge - start, cnt, ge - gs);     // {first posting, postings, own count, group size}
+                } else if (MODE == 1 || MODE == 2) {
+                    if (ge - gs >= 2 && u + 1 == ge && (MODE == 1 || a.in_shard[po[j].x]))
+                        atomicAdd(&a.cost[po[j].x], (unsigned long long) (ge - gs));
+                }
+            }
+        }
+    }
+    if constexpr (PASS == 0) {
+#pragma unroll
+        for (int d = PDL_WAVE / 2; d > 0; d >>= 1) { n_rec += __shfl_xor(n_rec, d, PDL_WAVE); n_grp += __shfl_xor(n_grp, d, PDL_WAVE); }
+        __syncthreads();
+        if (tid < 2) s_red[tid] = 0;
+        __syncthreads();
+        if (lane == 0) { atomicAdd(&s_red[0], n_rec); atomicAdd(&s_red[1], n_grp); }
+        __syncthreads();
+        if (tid < 2 && s_red[tid]) atomicAdd(&a.counters[tid], (unsigned long long) s_red[tid]);
+        if constexpr (GENOMES) {
+            if (lds_table) for (uint32_t i = tid; i < a.n_genomes; i += GT_THREADS) {
+                if (s_full[i]) atomicAdd(&a.g_full[i], s_full[i]);
+                if (s_upper[i]) atomicAdd(&a.g_upper[i], s_upper[i]);
+            }
         }
     }
 }
 
-// total_visited (library.cpp:327) straight from the records: every record of a group with >= 2 records
-// adds the group size to its gene.  Only used in complexity-only mode (no range lists to sum over).
-__global__ __launch_bounds__(256) void k_record_costs(const uint2 *__restrict__ post, const uint32_t *__restrict__ gid,
-                                                      const uint32_t *__restrict__ goff, const uint64_t *d_u,
-                                                      unsigned long long *__restrict__ cost,
-                                                      unsigned long long *__restrict__ n_shared_records) {
-    __shared__ uint32_t s_cnt;
-    const uint32_t u_count = (uint32_t) *d_u;
-    if (threadIdx.x == 0) s_cnt = 0;
-    __syncthreads();
-    const uint32_t u = blockIdx.x * 256 + threadIdx.x;
-    bool shared = false;
-    if (u < u_count) {
-        const uint32_t g = gid[u];
-        const uint32_t len = goff[g + 1] - goff[g];
-        shared = len >= 2;
-        if (shared) atomicAdd(&cost[post[u].x], (unsigned long long) len);
-    }
-    const unsigned long long m = __ballot(shared);
-    if ((threadIdx.x & (PDL_WAVE - 1)) == 0 && m) atomicAdd(&s_cnt, (uint32_t) __popcll(m));
-    __syncthreads();
-    if (threadIdx.x == 0 && s_cnt) atomicAdd(n_shared_records, (unsigned long long) s_cnt);   // one per workgroup
-}
-
-// K-ranges: the per-gene posting-range lists (kmers_ranges, library.cpp:318-326) as flat uint4
-// {group start, group length, own count, 0}, gene major.  The reference appends to each gene's list
-// while walking the groups in rank order; here that is a transposition of the dictionary:
-//   1. one pass in dictionary order packs every record of a shared group as a 16-byte tuple and
-//      compacts (gene, tuple index) pairs                                   [coalesced]
-//   2. a stable radix sort of the pairs by gene gives gene-major order, rank order inside a gene
-//   3. one gather of the 16-byte tuples through the sorted indices          [one random 16 B read each]
-// (Slot allocation with global atomics was measured 4x slower than the sort: device-scope atomics on
-// scattered counters run at the memory side on this chip.)
-// MODE 0: whole groups for the genes of a shard | 1: upper ranges for every gene | 2: upper ranges for the genes of a shard
-template <int MODE> struct SharedFlag {              // the mode is a template parameter: the per-item code stays straight-line
-    const uint32_t *gid; const uint32_t *goff;
-    const uint2 *post; const uint8_t *in_shard;      // MODE 0, 2: only the genes of the shard get range lists
-    __device__ uint32_t operator()(uint64_t u) const {
-        const uint32_t g = gid[u];
-        const uint32_t gs = goff[g], ge = goff[g + 1];
-        const uint32_t shared = (uint32_t) (ge - gs >= 2);
-        if constexpr (MODE == 1) return shared & (uint32_t) ((uint32_t) u + 1 < ge);   // the last member of a group has nothing above it
-        else if constexpr (MODE == 2) return shared & (uint32_t) ((uint32_t) u + 1 < ge) & (uint32_t) in_shard[post[u].x];
-        else return shared & (uint32_t) in_shard[post[u].x];
-    }
-};
-struct SharedScatter {
-    const uint2 *post; const uint32_t *gid; const uint32_t *goff;
-    uint32_t *key2; uint4 *tuples;
-    uint32_t upper_only;       // 1: a gene's range covers only the postings AFTER its own record (genes above it)
-    unsigned long long *cost;  // upper_only: the group size of a group's last member is added here (it has no range)
-    const uint8_t *in_shard;   // upper_only with a shard: only its genes keep costs
-    struct Loaded { uint32_t gs, ge; uint2 po; };
-    __device__ Loaded load(uint64_t u, uint32_t) const {
-        const uint32_t g = gid[u];
-        return Loaded{goff[g], goff[g + 1], post[u]};
-    }
-    __device__ void store(uint64_t u, uint32_t f, uint32_t prefix, const Loaded &v) const {
-        if (!f) {
-            if (upper_only && v.ge - v.gs >= 2 && (uint32_t) u + 1 == v.ge && (!in_shard || in_shard[v.po.x]))
-                atomicAdd(&cost[v.po.x], (unsigned long long) (v.ge - v.gs));
-            return;
-        }
-        const uint32_t start = upper_only ? (uint32_t) u + 1 : v.gs;
-        key2[prefix] = v.po.x;             // (the sort's values are the positions themselves)
-        tuples[prefix] = make_uint4(start, v.ge - start, v.po.y, v.ge - v.gs);      // {first posting, postings, own count, group size}
-    }
-};
 // Also adds up total_visited (library.cpp:327) = the group sizes over a gene's ranges: the list is gene-sorted, so a
 // wave holds one or two genes as a rule; one atomic per (wave, gene).
 __global__ __launch_bounds__(256) void k_gather_ranges(const uint32_t *__restrict__ idx_sorted, const uint32_t *__restrict__ key_sorted,
@@ -650,30 +736,34 @@ static void stage_alphabet_and_lengths(pdl_ctx *c, int kvalue, bool only_complex
     c->key64 = c->rp.rank_bits > 32;
 }
 
-// K-rank over the whole stream into (keys_a, vals_a)
+// K-rank over the whole stream into (keys_a, vals_a); d_bins != nullptr: also the interval histogram (multi-GPU build)
 template <class KeyT>
-static void stage_rank(pdl_ctx *c) {
+static void stage_rank(pdl_ctx *c, uint32_t *d_bins = nullptr, uint32_t bin_shift = 0) {
     hipStream_t st = c->stream;
     const uint64_t M = c->M;
     c->keys_a.alloc(M * sizeof(KeyT)); c->keys_b.alloc(M * sizeof(KeyT));
     c->vals_a.alloc(M * sizeof(uint32_t)); c->vals_b.alloc(M * sizeof(uint32_t));
     if (c->rp.hash_fallback) {
         if constexpr (sizeof(KeyT) == 8) {
-            hipLaunchKernelGGL(k_rank_hash<0>, dim3((c->N + 255) / 256), dim3(256), 0, st, c->d_res, c->d_off,
-                               c->kmer_off.as<uint64_t>(), c->N, c->rp, c->keys_a.as<uint64_t>(), c->vals_a.as<uint32_t>(), (uint32_t *) nullptr);
+            if (d_bins) hipLaunchKernelGGL(k_rank_hash<1>, dim3((c->N + 255) / 256), dim3(256), 0, st, c->d_res, c->d_off,
+                                           c->kmer_off.as<uint64_t>(), c->N, c->rp, c->keys_a.as<uint64_t>(), c->vals_a.as<uint32_t>(), d_bins);
+            else hipLaunchKernelGGL(k_rank_hash<0>, dim3((c->N + 255) / 256), dim3(256), 0, st, c->d_res, c->d_off,
+                                    c->kmer_off.as<uint64_t>(), c->N, c->rp, c->keys_a.as<uint64_t>(), c->vals_a.as<uint32_t>(), (uint32_t *) nullptr);
         }
     } else {
         const uint64_t tiles = (M + RANK_TILE - 1) / RANK_TILE;
-        hipLaunchKernelGGL((k_rank<KeyT, 0>), dim3((uint32_t) tiles), dim3(RANK_THREADS), 0, st, c->d_res, c->d_off,
-                           c->kmer_off.as<uint64_t>(), c->N, M, c->R, c->rp, c->keys_a.as<KeyT>(), c->vals_a.as<uint32_t>(), 0u, (uint32_t *) nullptr);
+        if (d_bins) hipLaunchKernelGGL((k_rank<KeyT, 1>), dim3((uint32_t) std::min<uint64_t>(tiles, 2048)), dim3(RANK_THREADS), 0, st, c->d_res, c->d_off,
+                                       c->kmer_off.as<uint64_t>(), c->N, M, c->R, c->rp, c->keys_a.as<KeyT>(), c->vals_a.as<uint32_t>(), bin_shift, d_bins);
+        else hipLaunchKernelGGL((k_rank<KeyT, 0>), dim3((uint32_t) tiles), dim3(RANK_THREADS), 0, st, c->d_res, c->d_off,
+                                c->kmer_off.as<uint64_t>(), c->N, M, c->R, c->rp, c->keys_a.as<KeyT>(), c->vals_a.as<uint32_t>(), 0u, (uint32_t *) nullptr);
     }
     PDL_HIP(hipGetLastError());
 }
 
-// K-sort + K-rle over the first m elements of (keys_in, vals_in): records into c->post / recpos / ghead (in keys_a).
+// K-sort + K-rle over the first m elements of (keys_in, vals_in): records into c->post / recpos.
 // d_scal[0] receives the record count.
 template <class KeyT>
-static void stage_sort_and_dedup(pdl_ctx *c, KeyT *keys_in, KeyT *keys_out, uint32_t *vals_in, uint32_t *vals_out, uint64_t m, bool pack_head) {
+static void stage_sort_and_dedup(pdl_ctx *c, KeyT *keys_in, KeyT *keys_out, uint32_t *vals_in, uint32_t *vals_out, uint64_t m) {
     uint64_t *d_scal = c->scalars.as<uint64_t>();
     ev_begin(c, EV_SORT1);
     pdl_sort_pairs<KeyT>(c, keys_in, keys_out, vals_in, vals_out, m, c->rp.rank_bits);
@@ -686,23 +776,52 @@ static void stage_sort_and_dedup(pdl_ctx *c, KeyT *keys_in, KeyT *keys_out, uint
     ev_begin(c, EV_DICT);                                       // (ended by the caller, behind K-groups where it runs them)
     c->recpos.alloc((m + 1) * sizeof(uint32_t));
     c->post.alloc(m * sizeof(uint2));                           // U <= m records (sized before U is known)
-    uint8_t *ghead = reinterpret_cast<uint8_t *>(c->keys_a.p);   // keys_a is free after the sort (>= m bytes)
     scan_and_apply(c, m, RecHead<KeyT>{skeys, svals},
-                   RecScatter<KeyT>{skeys, svals, m, c->recpos.as<uint32_t>(), c->post.as<uint2>(), ghead, pack_head ? 1u : 0u}, d_scal + 0);
+                   RecScatter<KeyT>{skeys, svals, m, c->recpos.as<uint32_t>(), c->post.as<uint2>()}, d_scal + 0);
 }
 
-// K-ranges + K-cost over the grouped dictionary (post/gid/goff hold `bound` records at most, the count is at d_scal[0]).
-//   mode 0: whole groups for the shard's genes | 1: upper ranges, every gene | 2: upper ranges, the shard's genes
-static void stage_ranges_and_costs(pdl_ctx *c, uint64_t bound, int mode, bool only_complexity) {
+// Launch helper of k_group_tiles: persistent workgroups over the tiles.
+template <int PASS, int MODE, bool GENOMES, bool RECORD_COSTS>
+static void launch_group_tiles(pdl_ctx *c, const GroupTileArgs &a) {
+    const uint64_t tiles = (a.n_bound + GT_TILE - 1) / GT_TILE;
+    int cus = c->cus;
+    if (cus <= 0) {
+        cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) cus = prop.multiProcessorCount;
+        c->cus = cus;
+    }
+    const uint32_t grid = (uint32_t) std::max<uint64_t>(1, std::min<uint64_t>(tiles, (uint64_t) cus * (GENOMES ? 2 : 8)));
+    hipLaunchKernelGGL((k_group_tiles<PASS, MODE, GENOMES, RECORD_COSTS>), dim3(grid), dim3(GT_THREADS), 0, c->stream, a);
+    PDL_HIP(hipGetLastError());
+}
+
+// K-groups + K-ranges + K-cost over the dictionary (postings with head bits; `bound` records at most, the count is at
+// d_scal[0]).  mode 0: whole groups for the shard's genes | 1: upper ranges, every gene | 2: upper ranges, the shard's genes.
+// genomes_pass: the COUNT pass also adds up every genome's lookups (multi-GPU: behind the control block's K-cost words).
+static void stage_ranges_and_costs(pdl_ctx *c, uint64_t bound, int mode, bool only_complexity, bool genomes_pass) {
     hipStream_t st = c->stream;
     uint64_t *d_scal = c->scalars.as<uint64_t>();
     const uint64_t *d_u = d_scal + 0;
     uint2 *post = pdl_postings(c);
-    const uint32_t ublocks = (uint32_t) ((bound + 255) / 256);
-    if (only_complexity) {                   // (cost[] was zeroed by K-len's apply, d_scal[2] with the control block)
-        hipLaunchKernelGGL(k_record_costs, dim3(ublocks), dim3(256), 0, st, post, c->gid.as<uint32_t>(),
-                           c->goff.as<uint32_t>(), d_u, c->cost.as<unsigned long long>(),
-                           reinterpret_cast<unsigned long long *>(d_scal + 2));
+    const uint64_t tiles = (bound + GT_TILE - 1) / GT_TILE;
+    if (tiles > 0x7fffffffull) PDL_FAIL(PDL_ERR_UNSUPPORTED, "dictionary of %llu records exceeds the grid limit", (unsigned long long) bound);
+    c->scan_tmp.alloc((size_t) tiles * 3 * sizeof(uint32_t));
+    GroupTileArgs ga{};
+    ga.post = post; ga.n_bound = bound; ga.d_n = d_u;
+    ga.tile_sums = c->scan_tmp.as<uint32_t>(); ga.th_first = ga.tile_sums + tiles; ga.th_last = ga.th_first + tiles;
+    ga.cost = c->cost.as<unsigned long long>();
+    ga.counters = reinterpret_cast<unsigned long long *>(d_scal + 10);
+    ga.genome_of = c->d_gen; ga.n_genomes = c->G;
+    ga.g_full = reinterpret_cast<unsigned long long *>(d_scal + PDL_CTL_GCOST) + c->G;
+    if (genomes_pass) {              // (the lookups above the diagonal are added up as well; only the deal's own pass reads them)
+        c->scratch2.alloc(std::max<size_t>(c->scratch2.bytes, (size_t) c->G * sizeof(uint64_t)));
+        PDL_HIP(hipMemsetAsync(c->scratch2.p, 0, (size_t) c->G * sizeof(uint64_t), st));
+        ga.g_upper = c->scratch2.as<unsigned long long>();
+    }
+    hipLaunchKernelGGL(k_fold_last_record, dim3(1), dim3(1024), 0, st, post, c->post_ext ? (uint32_t *) nullptr : c->recpos.as<uint32_t>(), d_u);
+    if (only_complexity) {                   // (cost[] was zeroed by K-len's apply, the counters with the control block)
+        launch_group_tiles<0, 3, false, true>(c, ga);
     } else {
         ev_begin(c, EV_SORT2);
         // scratch layout: tuples uint4[bound] | v2a u32[bound] | k2b u32[bound] | v2b u32[bound]; key2 lives in vals_a (free after sort 1)
@@ -713,7 +832,6 @@ static void stage_ranges_and_costs(pdl_ctx *c, uint64_t bound, int mode, bool on
         uint32_t *v2a = reinterpret_cast<uint32_t *>(tuples + bound);
         uint32_t *k2b = v2a + bound;
         uint32_t *v2b = k2b + bound;
-        const uint8_t *in_shard = nullptr;
         if (mode != 1) {                    // only the genes this context scores need range lists
             std::vector<uint8_t> &h = c->h_seq_in_shard;   // lives in the context: the copy below needs no synchronisation
             h.assign((size_t) c->N, 0);
@@ -722,49 +840,58 @@ static void stage_ranges_and_costs(pdl_ctx *c, uint64_t bound, int mode, bool on
             for (uint32_t i = 0; i < c->N; i++) h[i] = gsel[c->h_genome_of[i]];
             c->seq_in_shard.alloc(c->N);
             PDL_HIP(hipMemcpyAsync(c->seq_in_shard.p, h.data(), c->N, hipMemcpyHostToDevice, st));
-            in_shard = c->seq_in_shard.as<uint8_t>();
+            ga.in_shard = c->seq_in_shard.as<uint8_t>();
         }
-        const uint32_t upper_only = mode == 0 ? 0u : 1u;
-        const SharedScatter scatter{post, c->gid.as<uint32_t>(), c->goff.as<uint32_t>(), k2a, tuples,
-                                    upper_only, c->cost.as<unsigned long long>(), in_shard};
-        const uint64_t *d_us = d_scal + 2;       // ranges built = the scan's total
-        const uint32_t *gid = c->gid.as<uint32_t>(), *goff = c->goff.as<uint32_t>();
-        if (mode == 1) scan_and_apply(c, bound, SharedFlag<1>{gid, goff, post, nullptr}, scatter, d_scal + 2, nullptr, d_u);
-        else if (mode == 2) scan_and_apply(c, bound, SharedFlag<2>{gid, goff, post, in_shard}, scatter, d_scal + 2, nullptr, d_u);
-        else scan_and_apply(c, bound, SharedFlag<0>{gid, goff, post, in_shard}, scatter, d_scal + 2, nullptr, d_u);
-        c->upper_only = upper_only != 0;
+        ga.key2 = k2a; ga.tuples = tuples;
+        const uint64_t *d_us = d_scal + 2;       // ranges built = the total of the tile counts
+        if (mode == 1) launch_group_tiles<0, 1, false, false>(c, ga);
+        else if (mode == 2) { if (genomes_pass) launch_group_tiles<0, 2, true, false>(c, ga); else launch_group_tiles<0, 2, false, false>(c, ga); }
+        else launch_group_tiles<0, 0, false, false>(c, ga);
+        hipLaunchKernelGGL(k_scan_tile_scan, dim3(1), dim3(1024), 0, st, ga.tile_sums, (uint32_t) tiles, d_scal + 2, (uint64_t *) nullptr);
+        if (mode == 1) launch_group_tiles<1, 1, false, false>(c, ga);
+        else if (mode == 2) launch_group_tiles<1, 2, false, false>(c, ga);
+        else launch_group_tiles<1, 0, false, false>(c, ga);
+        c->upper_only = mode != 0;
         const uint32_t seq_bits = std::max<uint32_t>(1, bit_length64(c->N ? c->N - 1 : 0));
-        pdl_sort_pairs<uint32_t>(c, k2a, k2b, v2a, v2b, bound, seq_bits, true, d_us);     // values = tuple positions; sorted pairs now in (k2b, v2b)
+        // One GPU: the range count stays on the device, the kernels behind it are sized for the bound.  Multi-GPU: a rank
+        // builds ranges for 1/world of the records, so it reads the count (one synchronisation) and sizes them exactly.
+        uint64_t n_sort = bound;
+        const uint64_t *d_sort_n = d_us;
+        if (c->dist) {
+            PinRead rd(c);
+            const uint64_t *pn = rd.add<uint64_t>(d_us, 1);
+            rd.sync();
+            n_sort = pn[0]; d_sort_n = nullptr;
+        }
+        pdl_sort_pairs<uint32_t>(c, k2a, k2b, v2a, v2b, n_sort, seq_bits, true, d_sort_n);     // values = tuple positions; sorted pairs now in (k2b, v2b)
         ev_end(c, EV_SORT2);
 
         ev_begin(c, EV_RANGES);
-        c->ranges.alloc(bound * sizeof(uint4));
+        c->ranges.alloc(std::max<uint64_t>(n_sort, 1) * sizeof(uint4));
         c->seq_off.alloc(((size_t) c->N + 1) * sizeof(uint32_t));
-        hipLaunchKernelGGL(k_gather_ranges, dim3(ublocks), dim3(256), 0, st, v2b, k2b, tuples, d_us, c->ranges.as<uint4>(), c->cost.as<unsigned long long>());
+        const uint32_t gblocks = (uint32_t) std::max<uint64_t>((n_sort + 255) / 256, 1);
+        hipLaunchKernelGGL(k_gather_ranges, dim3(gblocks), dim3(256), 0, st, v2b, k2b, tuples, d_us, c->ranges.as<uint4>(), c->cost.as<unsigned long long>());
         hipLaunchKernelGGL(k_seq_offsets, dim3((c->N + 1 + 255) / 256), dim3(256), 0, st, k2b, d_us, c->N, c->seq_off.as<uint32_t>());
         PDL_HIP(hipGetLastError());
         ev_end(c, EV_RANGES);
     }
 
-    // K-cost; U' and the number of shared groups over the whole dictionary (one light pass over gid/goff; the multi-GPU
-    // build has them already from its per-genome pass)
+    // K-cost
     unsigned long long *d_gcost = reinterpret_cast<unsigned long long *>(d_scal + PDL_CTL_GCOST);
     hipLaunchKernelGGL(k_genome_cost, dim3((c->N + 255) / 256), dim3(256), 0, st, c->cost.as<unsigned long long>(),
                        c->kseq_len.as<uint32_t>(), c->d_gen, c->N, d_gcost,
                        reinterpret_cast<unsigned long long *>(d_scal + 4), reinterpret_cast<unsigned long long *>(d_scal + 7),
                        reinterpret_cast<unsigned long long *>(d_scal + 8));
-    if (!c->dist)
-        hipLaunchKernelGGL(k_dictionary_counters<false>, dim3((uint32_t) std::min<uint64_t>(ublocks, 1024)), dim3(256), 0, st, post, c->gid.as<uint32_t>(),
-                           c->goff.as<uint32_t>(), d_u, (const uint32_t *) nullptr, 0u, reinterpret_cast<unsigned long long *>(d_scal + 10),
-                           (unsigned long long *) nullptr, (unsigned long long *) nullptr);
     PDL_HIP(hipGetLastError());
 
     uint64_t tail[12] = {0};
     {
         PinRead rd(c);                       // one copy: the whole control block
-        const uint64_t *pt = rd.add<uint64_t>(d_scal, PDL_CTL_GCOST + c->G);
+        const uint64_t *pt = rd.add<uint64_t>(d_scal, PDL_CTL_GCOST + 2 * (size_t) c->G);
         rd.sync();
-        if (!c->dist) c->h_genome_cost.assign(pt + PDL_CTL_GCOST, pt + PDL_CTL_GCOST + c->G);     // (multi-GPU: every genome's cost is known already)
+        // one GPU / a plain shard: per-genome costs from the per-gene ones; multi-GPU: every genome's cost from the COUNT pass
+        const uint64_t *pg = pt + PDL_CTL_GCOST + (genomes_pass ? c->G : 0);
+        c->h_genome_cost.assign(pg, pg + c->G);
         memcpy(tail, pt, sizeof(tail));
     }
     c->U = tail[0];
@@ -779,28 +906,18 @@ static void stage_ranges_and_costs(pdl_ctx *c, uint64_t bound, int mode, bool on
 
 template <class KeyT>
 static void dictionary_pipeline(pdl_ctx *c, bool only_complexity) {
-    hipStream_t st = c->stream;
     const uint64_t M = c->M;
-    uint64_t *d_scal = c->scalars.as<uint64_t>();
     ev_begin(c, EV_RANK);
     stage_rank<KeyT>(c);
     ev_end(c, EV_RANK);
     KeyT *keys_in = c->keys_a.as<KeyT>(), *keys_out = c->keys_b.as<KeyT>();
     uint32_t *vals_in = c->vals_a.as<uint32_t>(), *vals_out = c->vals_b.as<uint32_t>();
-    stage_sort_and_dedup<KeyT>(c, keys_in, keys_out, vals_in, vals_out, M, false);
+    stage_sort_and_dedup<KeyT>(c, keys_in, keys_out, vals_in, vals_out, M);
+    ev_end(c, EV_DICT);
     if (!only_complexity) pdl_prepare_tasks(c);     // host work + small uploads while the device sorts
     // U (records) and the range count stay on the device until the end of the build: everything below is sized and
     // launched for the bound M and reads the counts there — no host round trip in the middle of the pipeline
-    const uint64_t *d_u = d_scal + 0;
-    c->gid.alloc(M * sizeof(uint32_t));
-    c->goff.alloc((M + 2) * sizeof(uint32_t));
-    const uint8_t *ghead = reinterpret_cast<const uint8_t *>(c->keys_a.p);
-    scan_and_apply(c, M, GroupHeadFlag{ghead, d_u}, GroupScatter{c->gid.as<uint32_t>(), c->goff.as<uint32_t>(), d_u}, d_scal + 1, nullptr, d_u);
-    hipLaunchKernelGGL(k_fold_last_record, dim3(1), dim3(1024), 0, st, c->post.as<uint2>(), c->recpos.as<uint32_t>(), c->goff.as<uint32_t>(),
-                       d_scal + 1, d_u);
-    PDL_HIP(hipGetLastError());
-    ev_end(c, EV_DICT);
-    stage_ranges_and_costs(c, M, c->dict_shard.empty() ? 1 : 0, only_complexity);
+    stage_ranges_and_costs(c, M, c->dict_shard.empty() ? 1 : 0, only_complexity, false);
 }
 
 void pdl_run_preprocess(pdl_ctx *c, int kvalue, bool only_complexity) {
@@ -833,25 +950,13 @@ static void dist_slice_pipeline(pdl_ctx *c) {
     const uint64_t M = c->M;
     uint64_t *d_scal = c->scalars.as<uint64_t>();
     const uint32_t W = c->world, me = c->rank;
-    // 1. k-mers per bin of the rank space (top DIST_BIN_BITS bits of a rank)
+    // 1. every k-mer's rank, and as a by-product the k-mers per bin of the rank space (top DIST_BIN_BITS bits of a rank)
     ev_begin(c, EV_RANK);
     const uint32_t shift = c->rp.rank_bits > DIST_BIN_BITS ? c->rp.rank_bits - DIST_BIN_BITS : 0;
     c->scratch2.alloc(std::max<size_t>(c->scratch2.bytes, DIST_BINS * sizeof(uint32_t)));
     uint32_t *d_bins = c->scratch2.as<uint32_t>();
     PDL_HIP(hipMemsetAsync(d_bins, 0, DIST_BINS * sizeof(uint32_t), st));
-    c->keys_a.alloc(M * sizeof(KeyT));
-    if (c->rp.hash_fallback) {
-        if constexpr (sizeof(KeyT) == 8)
-            hipLaunchKernelGGL(k_rank_hash<1>, dim3((c->N + 255) / 256), dim3(256), 0, st, c->d_res, c->d_off, c->kmer_off.as<uint64_t>(), c->N,
-                               c->rp, (uint64_t *) nullptr, (uint32_t *) nullptr, d_bins);
-    } else {
-        const uint64_t tiles = (M + RANK_TILE - 1) / RANK_TILE;
-        hipLaunchKernelGGL((k_rank<KeyT, 1>), dim3((uint32_t) std::min<uint64_t>(tiles, 1024)), dim3(RANK_THREADS), 0, st, c->d_res, c->d_off,
-                           c->kmer_off.as<uint64_t>(), c->N, M, c->R, c->rp, (KeyT *) nullptr, (uint32_t *) nullptr, shift, d_bins);
-    }
-    PDL_HIP(hipGetLastError());
-    // 2. the ranks themselves (queued behind the count; the host reads the bins meanwhile)
-    stage_rank<KeyT>(c);
+    stage_rank<KeyT>(c, d_bins, shift);
     ev_end(c, EV_RANK);
     std::vector<uint64_t> pre(DIST_BINS + 1, 0);
     {
@@ -881,7 +986,19 @@ static void dist_slice_pipeline(pdl_ctx *c) {
     if (m_own) {
         KeyT *keys_in = sel_k, *keys_out = c->keys_a.as<KeyT>();
         uint32_t *vals_in = sel_v, *vals_out = c->vals_a.as<uint32_t>();
-        stage_sort_and_dedup<KeyT>(c, keys_in, keys_out, vals_in, vals_out, m_own, true);
+        stage_sort_and_dedup<KeyT>(c, keys_in, keys_out, vals_in, vals_out, m_own);
+        // every genome's lookups above the diagonal inside this run (groups never straddle runs): summed over the ranks
+        // they are the weights of the genome deal (the fold of the globally last record is not in them: they only balance)
+        const uint64_t tiles = (m_own + GT_TILE - 1) / GT_TILE;
+        c->scan_tmp.alloc((size_t) tiles * 3 * sizeof(uint32_t));
+        GroupTileArgs ga{};
+        ga.post = c->post.as<uint2>(); ga.n_bound = m_own; ga.d_n = d_scal + 0;
+        ga.tile_sums = c->scan_tmp.as<uint32_t>(); ga.th_first = ga.tile_sums + tiles; ga.th_last = ga.th_first + tiles;
+        ga.counters = reinterpret_cast<unsigned long long *>(d_scal + 12);      // (scratch words: the real counters come from the finish)
+        ga.genome_of = c->d_gen; ga.n_genomes = c->G;
+        ga.g_full = reinterpret_cast<unsigned long long *>(d_scal + PDL_CTL_GCOST);             // scratch here, cleared again by the finish
+        ga.g_upper = reinterpret_cast<unsigned long long *>(d_scal + PDL_CTL_GCOST) + c->G;
+        launch_group_tiles<0, 3, true, false>(c, ga);
         ev_end(c, EV_DICT);
     } else {
         c->post.alloc(16);
@@ -896,11 +1013,14 @@ void pdl_run_dist_begin(pdl_ctx *c, int kvalue) {
     stage_alphabet_and_lengths(c, kvalue, false);
     if (c->key64) dist_slice_pipeline<uint64_t>(c); else dist_slice_pipeline<uint32_t>(c);
     ev_end(c, EV_DIST_BEGIN);
+    c->h_run_weights.assign(c->G, 0);
     if (c->M_slice) {
         PinRead rd(c);
         const uint64_t *pu = rd.add<uint64_t>(c->scalars.as<uint64_t>(), 1);
+        const uint64_t *pw = rd.add<uint64_t>(c->scalars.as<uint64_t>() + PDL_CTL_GCOST + c->G, c->G);
         rd.sync();
         c->U_slice = pu[0];
+        c->h_run_weights.assign(pw, pw + c->G);
     } else {
         PDL_HIP(hipStreamSynchronize(st));
     }
@@ -928,45 +1048,48 @@ static void lpt_owner(const std::vector<uint64_t> &w, uint32_t world, std::vecto
     }
 }
 
-void pdl_run_dist_finish(pdl_ctx *c, uint64_t total) {
+void pdl_run_dist_finish(pdl_ctx *c, uint64_t total, const uint64_t *weights) {
     hipStream_t st = c->stream;
     uint64_t *d_scal = c->scalars.as<uint64_t>();
     ev_begin(c, EV_DIST_FINISH);
     if (total == 0) PDL_FAIL(PDL_ERR_EMPTY, "empty dictionary");
     if (total >= 0xfffff000ull) PDL_FAIL(PDL_ERR_UNSUPPORTED, "a dictionary of %llu records needs 64-bit record indices", (unsigned long long) total);
-    uint2 *post = c->post_ext;
-    // the record count of the whole dictionary goes where the kernels expect it (d_scal[0]); the other counters restart
+    // the record count of the whole dictionary goes where the kernels expect it (d_scal[0]); the other counters and the
+    // per-genome words restart
     uint64_t *h_u = reinterpret_cast<uint64_t *>(c->pin);       // (pinned scratch; rewritten only by the next PinRead, which comes after a sync)
     if (!h_u) PDL_FAIL(PDL_ERR_DEVICE, "pinned scratch missing");
     h_u[0] = total;
     PDL_HIP(hipMemcpyAsync(d_scal + 0, h_u, sizeof(uint64_t), hipMemcpyHostToDevice, st));
     PDL_HIP(hipMemsetAsync(d_scal + 1, 0, 2 * sizeof(uint64_t), st));
-    PDL_HIP(hipMemsetAsync(d_scal + 9, 0, 3 * sizeof(uint64_t), st));
-    const uint64_t *d_u = d_scal + 0;
-    // K-groups over the gathered runs (library.cpp:289-335, the fold of the last record included)
-    c->gid.alloc(total * sizeof(uint32_t));
-    c->goff.alloc((total + 2) * sizeof(uint32_t));
-    scan_and_apply(c, total, GroupHeadFlagPacked{post, d_u}, GroupScatterStrip{c->gid.as<uint32_t>(), c->goff.as<uint32_t>(), d_u, post}, d_scal + 1);
-    hipLaunchKernelGGL(k_fold_last_record, dim3(1), dim3(1024), 0, st, post, (uint32_t *) nullptr, c->goff.as<uint32_t>(), d_scal + 1, d_u);
-    // every genome's lookups (the reference's count, and above the diagonal), U', shared groups
-    unsigned long long *d_full = reinterpret_cast<unsigned long long *>(d_scal + PDL_CTL_GCOST) + c->G;      // [G] behind the K-cost block
-    c->scratch2.alloc(std::max<size_t>(c->scratch2.bytes, 2 * (size_t) c->G * sizeof(uint64_t)));
-    unsigned long long *d_upper = c->scratch2.as<unsigned long long>();
-    PDL_HIP(hipMemsetAsync(d_upper, 0, (size_t) c->G * sizeof(uint64_t), st));
-    const uint32_t ublocks = (uint32_t) std::min<uint64_t>((total + 255) / 256, 1024);
-    hipLaunchKernelGGL(k_dictionary_counters<true>, dim3(ublocks), dim3(256), 0, st, post, c->gid.as<uint32_t>(), c->goff.as<uint32_t>(), d_u,
-                       c->d_gen, c->G, reinterpret_cast<unsigned long long *>(d_scal + 10), d_full, d_upper);
-    PDL_HIP(hipGetLastError());
+    PDL_HIP(hipMemsetAsync(d_scal + 9, 0, 4 * sizeof(uint64_t), st));
+    PDL_HIP(hipMemsetAsync(d_scal + PDL_CTL_GCOST, 0, 2 * (size_t) c->G * sizeof(uint64_t), st));
+    // genomes -> ranks by longest-processing-time on each genome's lookups above the diagonal: the caller's sum of the
+    // runs' weights, or — without one — an exact pass over the gathered dictionary first
     c->h_upper_cost.assign(c->G, 0);
-    {
-        PinRead rd(c);
-        const uint64_t *pf = rd.add<uint64_t>(d_full, c->G);
-        const uint64_t *pu = rd.add<uint64_t>(d_upper, c->G);
-        rd.sync();
-        c->h_genome_cost.assign(pf, pf + c->G);
-        c->h_upper_cost.assign(pu, pu + c->G);
+    if (weights) {
+        c->h_upper_cost.assign(weights, weights + c->G);
+    } else {
+        const uint64_t tiles = (total + GT_TILE - 1) / GT_TILE;
+        c->scan_tmp.alloc((size_t) tiles * 3 * sizeof(uint32_t));
+        c->scratch2.alloc(std::max<size_t>(c->scratch2.bytes, ((size_t) c->G + 2) * sizeof(uint64_t)));
+        PDL_HIP(hipMemsetAsync(c->scratch2.p, 0, ((size_t) c->G + 2) * sizeof(uint64_t), st));
+        GroupTileArgs ga{};
+        ga.post = c->post_ext; ga.n_bound = total; ga.d_n = nullptr;
+        ga.tile_sums = c->scan_tmp.as<uint32_t>(); ga.th_first = ga.tile_sums + tiles; ga.th_last = ga.th_first + tiles;
+        ga.counters = c->scratch2.as<unsigned long long>() + c->G;
+        ga.genome_of = c->d_gen; ga.n_genomes = c->G;
+        ga.g_upper = c->scratch2.as<unsigned long long>();
+        ga.g_full = reinterpret_cast<unsigned long long *>(d_scal + PDL_CTL_GCOST);       // (scratch: the K-cost words are cleared below)
+        // (the fold of the last record is not applied yet: as with the callers' weights, these numbers only balance)
+        launch_group_tiles<0, 3, true, false>(c, ga);
+        {
+            PinRead rd(c);
+            const uint64_t *pu = rd.add<uint64_t>(ga.g_upper, c->G);
+            rd.sync();
+            c->h_upper_cost.assign(pu, pu + c->G);
+        }
+        PDL_HIP(hipMemsetAsync(d_scal + PDL_CTL_GCOST, 0, 2 * (size_t) c->G * sizeof(uint64_t), st));
     }
-    // genomes -> ranks; this rank's shard
     lpt_owner(c->h_upper_cost, c->world, c->h_owner);
     c->shard.clear();
     for (uint32_t g = 0; g < c->G; g++) if (c->h_owner[g] == c->rank) c->shard.push_back(g);
@@ -974,7 +1097,7 @@ void pdl_run_dist_finish(pdl_ctx *c, uint64_t total) {
     c->dict_shard = c->shard;
     c->tasks_ready = false;
     pdl_prepare_tasks(c);
-    stage_ranges_and_costs(c, total, 2, false);
+    stage_ranges_and_costs(c, total, 2, false, true);
     ev_end(c, EV_DIST_FINISH);
     ev_end(c, EV_PRE_TOTAL);
     PDL_HIP(hipStreamSynchronize(st));

@@ -152,10 +152,15 @@ class DistributedPangenes:
         ptr, records, _ = nat.dist_preprocess_begin(k, t_res.data_ptr(), t_off.data_ptr(), t_gen.data_ptr(), n_genes, n_residues,
                                                     W, r, keepalive=(t_res, t_off, t_gen))
         t0 = time.perf_counter()
-        cnt = torch.tensor([records], dtype=torch.int64, device=self.dev if self.on_device else None)
-        allc = torch.empty(W, dtype=torch.int64, device=cnt.device)
-        dist.all_gather_into_tensor(allc, cnt)
-        offs = exclusive_offsets(allc.cpu().numpy())
+        # one small all-gather: [records of my run | every genome's lookups inside it]; their sum deals the genomes
+        mine = torch.from_numpy(np.concatenate([[records], nat.run_weights]).astype(np.int64))
+        if self.on_device:
+            mine = mine.to(self.dev)
+        allv = torch.empty(W * mine.numel(), dtype=torch.int64, device=mine.device)       # (flat: gloo takes no 2-D output)
+        dist.all_gather_into_tensor(allv, mine)
+        allv = allv.cpu().numpy().reshape(W, -1)
+        offs = exclusive_offsets(allv[:, 0])
+        weights = allv[:, 1:].sum(axis=0)
         total = int(offs[-1])
         full = torch.empty(max(total, 1), dtype=torch.int64, device=self.dev)      # 8-byte records {gene, count|flag}
         if records:
@@ -164,7 +169,7 @@ class DistributedPangenes:
         if self.on_device:
             torch.cuda.current_stream(self.dev).synchronize()
         self.exchange_s["dictionary"] = time.perf_counter() - t0
-        nat.dist_preprocess_finish(full.data_ptr(), total, keepalive=full)
+        nat.dist_preprocess_finish(full.data_ptr(), total, genome_weights=weights, keepalive=full)
         return nat.cost
 
     def score_all(self):
@@ -193,7 +198,8 @@ class DistributedPangenes:
             dist.all_to_all_single(h_recv, send[:n_out].cpu(), output_split_sizes=[int(x) for x in recv_counts],
                                    input_split_sizes=[int(x) for x in send_counts])
             recv[:n_in].copy_(h_recv)
-            torch.cuda.synchronize(self.dev)
+            if self.dev.type == "cuda":
+                torch.cuda.synchronize(self.dev)
         self.exchange_s["cells"] = time.perf_counter() - t0
         nat.dist_score_finish(recv.data_ptr(), n_in, keepalive=recv)
 
@@ -209,9 +215,10 @@ class LocalRanks:
     Same library calls in the same order as ``DistributedPangenes``; per-rank device times come from the
     contexts' own HIP-event timings (``tools/shard_step_time.py``)."""
 
-    def __init__(self, world: int, device: int = -1, stream=None, flags: int = 0):
+    def __init__(self, world: int, device: int = -1, stream=None, flags: int = 0, exchange_weights: bool = True):
         from .pangene_native import PangeneNative
         self.world = world
+        self.exchange_weights = exchange_weights      # False: every rank computes the deal's weights itself (one more pass)
         self.ranks = [PangeneNative.open(device=device, stream=stream, flags=flags) for _ in range(world)]
 
     def close(self):
@@ -226,6 +233,7 @@ class LocalRanks:
         offs = exclusive_offsets([rec for _, rec, _ in runs])
         total = int(offs[-1])
         self.run_records = [rec for _, rec, _ in runs]
+        weights = np.sum([n.run_weights for n in self.ranks], axis=0) if self.exchange_weights else None
         self.dictionaries = []
         for r, n in enumerate(self.ranks):
             full = torch.empty(max(total, 1), dtype=torch.int64, device=t_res.device)
@@ -234,7 +242,7 @@ class LocalRanks:
                     n.copy_device(full.data_ptr() + int(offs[p]) * 8, ptr, rec * 8)
             self.dictionaries.append(full)
         for n, full in zip(self.ranks, self.dictionaries):
-            n.dist_preprocess_finish(full.data_ptr(), total, keepalive=full)
+            n.dist_preprocess_finish(full.data_ptr(), total, genome_weights=weights, keepalive=full)
         self.owner = self.ranks[0].dist_genome_owner()
         for n in self.ranks[1:]:
             assert np.array_equal(n.dist_genome_owner(), self.owner), "ranks disagree on the genome deal"

@@ -145,17 +145,24 @@ class PangeneNative:
     # -- multi-GPU passes (one context per GPU; pandelos_amd.distributed moves the bytes in between) ------------
     def dist_preprocess_begin(self, k, d_residues: int, d_offsets: int, d_genome_of: int, n_sequences: int,
                               n_residues: int, world: int, rank: int, keepalive=None):
-        """-> (device pointer, records, k-mers) of this rank's run of the dictionary."""
+        """-> (device pointer, records, k-mers) of this rank's run of the dictionary; ``self.run_weights`` = every genome's
+        lookups above the diagonal inside the run (int64 [G])."""
         self._keep = keepalive
         sl = _lib.PdlDistSlice()
         self._check(self._lib.pdl_dist_preprocess_begin(self._ctx, d_residues, d_offsets, d_genome_of, n_sequences, n_residues,
                                                         int(k), int(world), int(rank), C.byref(sl)))
+        self.run_weights = np.array([sl.genome_weights[g] for g in range(sl.genomes)], dtype=np.int64)
         return sl.d_postings or 0, int(sl.records), int(sl.kmers)
 
-    def dist_preprocess_finish(self, d_postings_all: int, total_records: int, keepalive=None) -> None:
+    def dist_preprocess_finish(self, d_postings_all: int, total_records: int, genome_weights=None, keepalive=None) -> None:
+        """``genome_weights``: the ranks' ``run_weights`` summed (identical on every rank); None lets the library compute them."""
         self._keep_dict = keepalive
         self.cost = _lib.PdlCost()
-        self._check(self._lib.pdl_dist_preprocess_finish(self._ctx, d_postings_all, int(total_records), C.byref(self.cost)))
+        w = None
+        if genome_weights is not None:
+            w = np.ascontiguousarray(genome_weights, dtype=np.uint64)
+        self._check(self._lib.pdl_dist_preprocess_finish(self._ctx, d_postings_all, int(total_records),
+                                                         w.ctypes.data if w is not None else None, C.byref(self.cost)))
 
     def dist_genome_owner(self) -> np.ndarray:
         out = np.zeros(self.cost.genomes, np.uint32)

@@ -66,3 +66,93 @@ def test_two_gloo_ranks_cover_all_genomes_once():
         assert p.exitcode == 0
     assert tot_cells == full_cells and tot_cost == full_cost
     assert slowest == 1.0 and sorted(set(owner)) == [0, 1]
+
+
+# ---- the exchange logic of the multi-GPU driver, on CPU tensors ----------------------------------------------------
+class _FakeRank:
+    """Stands in for PangeneNative in DistributedPangenes: runs and outboxes with recognisable contents (rank and index
+    encoded in every word), so that the driver's offsets, split sizes and copy directions can be checked without a GPU."""
+
+    def __init__(self, rank, world, genomes=5):
+        import torch
+        self.rank, self.world, self.genomes = rank, world, genomes
+        self.records = 3 + 4 * rank                                   # uneven runs; rank 0 has the shortest
+        self.run = torch.arange(self.records, dtype=torch.int64) + (rank << 32)
+        self.run_weights = np.arange(genomes, dtype=np.int64) * (rank + 1)
+        self.cost = "cost"
+        # cells for rank d: (rank + 1) * (d + 2) of them, none for myself
+        self.counts = np.array([0 if d == rank else (rank + 1) * (d + 2) for d in range(world)], dtype=np.int64)
+        cells = []
+        for d in range(world):
+            for i in range(int(self.counts[d])):
+                cells.append([rank, d, i, 7, 8, 9])
+        self.outbox = torch.tensor(cells, dtype=torch.int32).reshape(-1, 6)
+        self.seen = {}
+
+    def copy_device(self, dst, src, nbytes):
+        import ctypes
+        ctypes.memmove(dst, src, nbytes)
+
+    def dist_preprocess_begin(self, k, *a, keepalive=None):
+        return self.run.data_ptr(), self.records, self.records
+
+    def dist_preprocess_finish(self, ptr, total, genome_weights=None, keepalive=None):
+        self.seen["dictionary"] = keepalive.clone()
+        self.seen["total"] = total
+        self.seen["weights"] = np.asarray(genome_weights).copy()
+
+    def dist_score_begin(self, world):
+        return self.outbox.data_ptr(), self.counts
+
+    def dist_score_finish(self, ptr, n, keepalive=None):
+        self.seen["inbox"] = keepalive[:n].clone()
+
+
+def _exchange_worker(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fake = _FakeRank(rank, world)
+        dp = D.DistributedPangenes(fake, torch.device("cpu"), device_collectives=False)
+        t = torch.zeros(1)
+        dp.preprocess(3, t, t, t, 1, 1)
+        dp.score_all()
+        out.put((rank, fake.seen["dictionary"].tolist(), fake.seen["total"], fake.seen["weights"].tolist(), fake.seen["inbox"].tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_driver_exchanges_runs_and_cells_in_rank_order(world):
+    import queue
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(400):
+        try:
+            r = out.get(timeout=0.5)
+            got[r[0]] = r[1:]
+        except queue.Empty:
+            assert all(p.is_alive() or p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+        if len(got) == world:
+            break
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    fakes = [_FakeRank(r, world) for r in range(world)]
+    dictionary = [int(x) for f in fakes for x in f.run.tolist()]                  # the runs in rank order = the dictionary
+    weights = np.sum([f.run_weights for f in fakes], axis=0).tolist()
+    for r in range(world):
+        d, total, w, inbox = got[r]
+        assert d[:total] == dictionary and total == len(dictionary) and w == weights
+        want = [[s, r, i, 7, 8, 9] for s in range(world) for i in range(int(fakes[s].counts[r]))]     # source-major, as all-to-all delivers
+        assert inbox == want

@@ -26,10 +26,10 @@ def _device_inputs(res, off, gen):
     return t_res, t_off, t_gen
 
 
-def _local(world, res, off, gen, k, flags=0):
+def _local(world, res, off, gen, k, flags=0, exchange_weights=True):
     from pandelos_amd.distributed import LocalRanks
     t = _device_inputs(res, off, gen)
-    lr = LocalRanks(world, flags=flags)
+    lr = LocalRanks(world, flags=flags, exchange_weights=exchange_weights)
     cost = lr.preprocess(k, *t, len(gen), len(res))
     return lr, cost
 
@@ -59,16 +59,18 @@ def test_ranks_together_reproduce_the_fixture(name, world):
     lr.close()
 
 
+@pytest.mark.parametrize("weights", [True, False])      # the deal's weights: summed from the runs by the caller / computed by every rank
 @pytest.mark.parametrize("world", [2, 4])
-def test_ranks_together_reproduce_the_reference_digest(world):
+def test_ranks_together_reproduce_the_reference_digest(world, weights):
     res, off, gen, k, d = H.load_large("synth_16x1000x300_k5")
-    lr, cost = _local(world, res, off, gen, k)
+    lr, cost = _local(world, res, off, gen, k, exchange_weights=weights)
     assert cost.total_cost == d["total_cost"]
     lr.score_all()
     H.assert_scores_match_digest(lambda g: lr.generate_scores_part(g).as_dict(), d, f"W={world}")
     # the deal balances what the join walks (lookups above the diagonal), within one genome's worth
     walked = [n.timings()["walked_lookups"] for n in lr.ranks]
-    assert sum(walked) * 2 == cost.total_cost - cost.shared_records
+    # (the deal's weights leave out the fold of the globally last record, library.cpp:300-306: at most one group's size off)
+    assert abs(sum(walked) * 2 - (cost.total_cost - cost.shared_records)) <= 2 * cost.sequences
     assert max(walked) - min(walked) <= max(walked) / 2
     lr.close()
 
@@ -99,7 +101,7 @@ def test_random_sets_sharded_match_the_oracle(seed):
         pytest.skip("no gene holds a k-mer (undefined in the reference)")
     ora = ob.Oracle(res, off, gen, k)
     world = 2 + seed % 3
-    lr, cost = _local(world, res, off, gen, k)
+    lr, cost = _local(world, res, off, gen, k, exchange_weights=bool(seed & 4))
     assert cost.total_cost == ora.total_cost
     lr.score_all()
     for g in range(ora.genomes):
@@ -150,7 +152,16 @@ def test_two_processes_over_torch_distributed_reproduce_the_digest():
     procs = [ctx.Process(target=_rank_main, args=(r, 2, port, name, out)) for r in range(2)]
     for p in procs:
         p.start()
-    got = [out.get(timeout=500) for _ in range(2)]
+    import queue
+    got = []
+    for _ in range(600):                                 # a rank that dies must fail the test at once, not after a long wait
+        try:
+            got.append(out.get(timeout=0.5))
+        except queue.Empty:
+            assert all(p.is_alive() or p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+        if len(got) == 2:
+            break
+    assert len(got) == 2
     for p in procs:
         p.join(60)
         assert p.exitcode == 0

@@ -160,8 +160,8 @@ class Runner:
         p_l, z_l, rows_l = tm["scored_lookups"], tm["emitted_cells"], tm["scored_rows"]
         join_bytes = 8.0 * p_l + 20.0 * z_l + 8.0 * rows_l * gs.genomes
         join_s = mean(join_ms) / 1e3
-        z_total, walked = D.all_reduce_sum([float(z_l), float(tm["walked_lookups"])], device=coll_dev)
-        p_total = float(cost.total_cost)
+        # (N > 1: a rank reports the cells, the walked postings and the reference-counted lookups of ITS genomes)
+        z_total, walked, p_total = D.all_reduce_sum([float(z_l), float(tm["walked_lookups"]), float(cost.total_cost)], device=coll_dev)
         bytes_alg_total = (cost.residues + 16.0 * cost.kmer_occurrences + 16.0 * cost.dictionary_records +
                            8.0 * p_total + 20.0 * z_total + 8.0 * gs.genes * gs.genomes)
         pairs = float(gs.genes) * float(gs.genes - 1)

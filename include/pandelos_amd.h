@@ -188,7 +188,10 @@ PDL_API int pdl_set_option(pdl_ctx *, const char *name, int64_t value);
  *   -- caller: all-to-all the per-destination counts, then the 24-byte cells --
  *   pdl_dist_score_finish       files the received cells with the local ones, folds them into the per-(row, genome) and
  *                               per-column maxima and puts every row in the reference's emission order.
- * Afterwards pdl_compute_scores / pdl_scores_counts work for the genomes of this rank (pdl_dist_genome_owner). */
+ * Afterwards pdl_compute_scores / pdl_scores_counts work for the genomes of this rank (pdl_dist_genome_owner).
+ * pdl_genome_cost and pdl_cost.total_cost cover this rank's genomes only (the reference prints "Genome g cost" from the
+ * task that scores g, library.cpp:535-538); "Total cost" is their sum over the ranks — a scalar all-reduce of the caller.
+ * The counters over the dictionary (records, shared records, groups) are complete on every rank. */
 typedef struct {
     const void *d_postings;   /* device, records x 8 bytes {gene u32, count u32 | group-head flag in bit 31} */
     uint64_t records;         /* unique (rank, gene) records of this rank's interval */

@@ -7,8 +7,8 @@
 //   K-rank    k_rank / k_rank_hash   per-gene k-mer ranks                    library.cpp:75-86,134-150
 //   K-sort    pdl_sort_pairs      stable LSD radix sort by rank              library.cpp:172-187,270-278
 //   K-rle     RecHead/RecScatter scan (records built in the apply)   dedup -> (rank,gene,count)   library.cpp:280-287
-//   K-groups  k_fold_last_record, k_group_tiles (group extents from head bits, per tile)  library.cpp:297-335
-//   K-ranges  k_group_tiles (range tuples), sort by gene, k_gather_ranges (+ per-gene cost), k_seq_offsets   library.cpp:312-327
+//   K-groups  k_fold_last_record, k_group_waves (group extents from head bits, per tile)  library.cpp:297-335
+//   K-ranges  k_group_waves (range tuples), sort by gene, k_gather_ranges (+ per-gene cost), k_seq_offsets   library.cpp:312-327
 //   K-cost    k_genome_cost       per-genome and total lookups               library.cpp:337-350,535-538
 //
 // HBM layout after this stage (what the join reads):
@@ -194,8 +194,14 @@ __global__ __launch_bounds__(RANK_THREADS) void k_rank(const uint8_t *__restrict
         const uint64_t qj = q0 + (uint64_t) j * RANK_THREADS + threadIdx.x;
         const uint64_t q = qj < m ? qj : m - 1;
         if (staged) {                                           // (uniform) boundaries from LDS: no chain of global loads
-            uint32_t a = 0, b = span;                           // last i in [0, span) with s_koff[i] <= q
-            while (a < b) { const uint32_t mid = (a + b) >> 1; if (s_koff[mid + 1] <= q) a = mid + 1; else b = mid; }
+            uint32_t a = 0;                                     // last i in [0, span) with s_koff[i] <= q
+            if (span <= 8) {                                    // (uniform, the usual case) count the gene starts at or below q:
+#pragma unroll                                                  //  independent broadcast reads instead of a dependent search
+                for (uint32_t i = 1; i < 8; i++) a += (uint32_t) (i < span && s_koff[i < span ? i : 0] <= q);
+            } else {
+                uint32_t b = span;
+                while (a < b) { const uint32_t mid = (a + b) >> 1; if (s_koff[mid + 1] <= q) a = mid + 1; else b = mid; }
+            }
             sq[j] = lo + a;
             pos[j] = s_off[a] + (q - s_koff[a]);
         } else {
@@ -340,7 +346,7 @@ template <class KeyT> struct SelApply {
 // K-groups + K-ranges, fused (library.cpp:289-335).  The dictionary arrives as postings {gene, count} in (rank, gene)
 // order with "opens a rank-group" in bit 31 of the count (set by K-rle; it is also the form the runs of a multi-GPU
 // build travel in).  A group is the records from one head to the next; nothing is materialised about groups: every
-// tile of 2048 records rebuilds the extents it needs from the head bits (a 64-bit ballot per wave and round, prev/next
+// tile of 1024 records (one wave) rebuilds the extents it needs from the head bits (a 64-bit ballot per round, prev/next
 // head by bit scans), looks beyond its borders only for the groups that cross them, and emits — for the records that
 // get a posting range — the 16-byte tuple {first posting, postings, own count, group size} and the gene as sort key:
 //
@@ -348,10 +354,10 @@ template <class KeyT> struct SelApply {
 //                        (library.cpp:300-306): a last record that opens a group of its own is folded into the preceding
 //                        group, moved to its gene-order place there (:312-315) and the head bits are put right, so that
 //                        from here on the bits alone say what the reference's groups are
-//   k_group_tiles<COUNT> ranges per tile (+ first/last head of every tile; + counters U', shared groups; + per-genome
+//   k_group_waves<COUNT> ranges per tile (+ first/last head of every tile; + counters U', shared groups; + per-genome
 //                        lookups; + per-gene costs in complexity-only mode)
 //   (scan of the tile counts)
-//   k_group_tiles<WRITE> tuples and keys at tile offset + position inside the tile (record order), the group size of a
+//   k_group_waves<WRITE> tuples and keys at tile offset + position inside the tile (record order), the group size of a
 //                        group's last member added to its gene's cost (it has no range of its own), head bits removed
 //
 // Two passes over the postings replace the group scan (gid/goff), the shared-record compaction and the counter pass
@@ -360,7 +366,6 @@ template <class KeyT> struct SelApply {
 // a bit another one may already have removed.
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t HEAD_BIT = 0x80000000u;
-constexpr int GT_THREADS = 256, GT_ITEMS = 8, GT_TILE = GT_THREADS * GT_ITEMS, GT_WORDS = GT_TILE / PDL_WAVE;      // 2048 records, 32 mask words
 constexpr uint32_t GT_NONE = 0xffffffffu;
 constexpr uint32_t COST_LDS_GENOMES = 4096;
 
@@ -433,7 +438,9 @@ struct GroupTileArgs {
     uint2 *post;
     uint64_t n_bound; const uint64_t *d_n;      // record count: on the device (at most n_bound) or n_bound itself
     const uint8_t *in_shard;                    // MODE 0, 2: the genes that get range lists
-    uint32_t *tile_sums;                        // [tiles] ranges per tile; exclusive-scanned between the passes
+    uint32_t *tile_sums;                        // [tiles] COUNT: ranges in the wave's tiles before this one
+    uint32_t *chunk_sums;                       // [waves] COUNT: ranges of a wave's tiles; exclusive-scanned between the passes
+    uint32_t tiles_per_chunk;                   // a wave owns this many consecutive tiles
     uint32_t *th_first, *th_last;               // [tiles] first / last head of a tile (GT_NONE: none), COUNT -> WRITE
     uint32_t *key2; uint4 *tuples;              // WRITE
     unsigned long long *cost;                   // per-gene total_visited (library.cpp:327): last members (WRITE), all shared records (COUNT, RECORD_COSTS)
@@ -442,113 +449,118 @@ struct GroupTileArgs {
     unsigned long long *g_full, *g_upper;       // COUNT, GENOMES: per genome, lookups as the reference counts them / above the diagonal
 };
 
+// One WAVE per tile of GW_TILE consecutive records, no LDS and no barrier on the data path: the head bits of a round of
+// 64 records are one ballot (a scalar register pair); previous / next head of a record come from bit scans of its
+// round's mask, from scalar scans over the rounds, and — for the groups that cross the tile's borders — from the
+// wave's previous tile (a wave owns consecutive tiles) and a peek at the 64 records behind the tile.  Only the first
+// tile of a wave's run looks back through memory, and only a group longer than that peek looks further ahead.
+// The ranges of a tile go to (scanned total of the waves before) + (running count of the wave) + rank inside the tile,
+// i.e. in record order.
 // MODE 0: whole groups for the genes of a shard | 1: the postings above the record, every gene | 2: those, for the genes
 // of a shard | 3: no ranges (counters / costs only).  PASS 0 = COUNT, 1 = WRITE.
+constexpr int GW_ROUNDS = 16, GW_TILE = GW_ROUNDS * PDL_WAVE, GW_THREADS = 256, GW_WAVES = GW_THREADS / PDL_WAVE;
 template <int PASS, int MODE, bool GENOMES, bool RECORD_COSTS>
-__global__ __launch_bounds__(GT_THREADS) void k_group_tiles(GroupTileArgs a) {
-    __shared__ unsigned long long s_mask[GT_WORDS];
-    __shared__ uint32_t s_prevw[GT_WORDS], s_nextw[GT_WORDS], s_cnt[GT_WORDS];
-    __shared__ uint32_t s_before, s_after, s_red[2];
-    __shared__ unsigned long long s_full[GENOMES ? COST_LDS_GENOMES : 1], s_upper[GENOMES ? COST_LDS_GENOMES : 1];
-    const uint32_t tid = threadIdx.x, lane = tid & (PDL_WAVE - 1), wave = tid / PDL_WAVE;
+__global__ __launch_bounds__(GW_THREADS) void k_group_waves(GroupTileArgs a) {
+    __shared__ uint32_t s_red[2];
+    extern __shared__ unsigned long long s_dyn[];        // GENOMES with <= COST_LDS_GENOMES genomes: full[G] | upper[G]
+    unsigned long long *s_full = s_dyn, *s_upper = s_dyn + a.n_genomes;
+    const uint32_t tid = threadIdx.x, lane = tid & (PDL_WAVE - 1);
+    const uint32_t gw = blockIdx.x * GW_WAVES + tid / PDL_WAVE;                  // this wave's index = its chunk of tiles
     const uint32_t n = (uint32_t) scan_count(a.n_bound, a.d_n);
-    const uint32_t tiles = (n + GT_TILE - 1) / GT_TILE, tiles_bound = (uint32_t) ((a.n_bound + GT_TILE - 1) / GT_TILE);
+    const uint32_t tiles = (n + GW_TILE - 1) / GW_TILE;
     const bool lds_table = GENOMES && a.n_genomes <= COST_LDS_GENOMES;
-    if constexpr (GENOMES) { if (lds_table) for (uint32_t i = tid; i < a.n_genomes; i += GT_THREADS) { s_full[i] = 0; s_upper[i] = 0; } }
-    uint32_t n_rec = 0, n_grp = 0;
-    for (uint32_t tile = blockIdx.x; tile < tiles_bound; tile += gridDim.x) {
-        if (tile >= tiles) {                             // (uniform) beyond the records: the scan over tiles_bound entries reads zeros
-            if (PASS == 0 && tid == 0) { a.tile_sums[tile] = 0; a.th_first[tile] = GT_NONE; a.th_last[tile] = GT_NONE; }
-            continue;
-        }
-        __syncthreads();                                 // the LDS words of the previous tile are done with
-        const uint32_t t0 = tile * GT_TILE;
-        uint2 po[GT_ITEMS];
+    if constexpr (GENOMES) { if (lds_table) { for (uint32_t i = tid; i < 2 * a.n_genomes; i += GW_THREADS) s_dyn[i] = 0; } }
+    if (tid < 2) s_red[tid] = 0;
+    __syncthreads();
+    const unsigned long long lt_mask = (1ull << lane) - 1ull, le_mask = (2ull << lane) - 1ull;
+    const uint32_t tile_lo = gw * a.tiles_per_chunk, tile_hi = min(tiles, tile_lo + a.tiles_per_chunk);
+    const uint32_t chunk_prefix = PASS == 1 ? a.chunk_sums[gw] : 0u;
+    uint32_t running = 0, n_rec = 0, n_grp = 0;
+    uint32_t last_head = GT_NONE;                        // (wave-uniform) last head in this wave's tiles so far
+    for (uint32_t tile = tile_lo; tile < tile_hi; tile++) {
+        const uint32_t t0 = tile * GW_TILE, t1 = min(t0 + (uint32_t) GW_TILE, n);
+        uint2 po[GW_ROUNDS];
 #pragma unroll
-        for (int j = 0; j < GT_ITEMS; j++) {             // all loads first, branch-free
-            const uint32_t u = t0 + j * GT_THREADS + tid;
+        for (int j = 0; j < GW_ROUNDS; j++) {            // all loads first, branch-free
+            const uint32_t u = t0 + j * PDL_WAVE + lane;
             po[j] = a.post[u < n ? u : n - 1];
         }
+        // the 64 records behind the tile: where the group that runs out of it ends (WRITE: only inside the wave's own
+        // tiles, whose head bits it has not removed yet; beyond them the COUNT pass's per-tile heads answer)
+        const bool may_peek = PASS == 0 || tile + 1 < tile_hi;
+        const uint32_t pu = t1 + lane;
+        const uint32_t peek = (may_peek && pu < n) ? a.post[pu].y >> 31 : 0u;
+        // (shard modes) "this gene gets ranges" for all sixteen records at once: behind the ballots below each lookup would
+        // wait for the one before it
+        uint32_t ins = 0xffffffffu;
+        if constexpr (MODE == 0 || MODE == 2) {
+            uint8_t inb[GW_ROUNDS];
 #pragma unroll
-        for (int j = 0; j < GT_ITEMS; j++) {
-            const uint32_t u = t0 + j * GT_THREADS + tid;
-            const unsigned long long m = __ballot(u < n && (po[j].y >> 31));
-            if (lane == 0) s_mask[j * (GT_THREADS / PDL_WAVE) + wave] = m;
+            for (int j = 0; j < GW_ROUNDS; j++) inb[j] = a.in_shard[po[j].x];
+            ins = 0;
+#pragma unroll
+            for (int j = 0; j < GW_ROUNDS; j++) ins |= (uint32_t) (inb[j] != 0) << j;
         }
-        __syncthreads();
-        if (wave == 0) {                                 // per mask word: last head in the words before, first head in the words after
-            const unsigned long long mw = lane < GT_WORDS ? s_mask[lane] : 0ull;
-            const unsigned long long has = __ballot(mw != 0) & ((1ull << GT_WORDS) - 1ull);
-            if (lane < GT_WORDS) {
-                const unsigned long long lower = has & ((1ull << lane) - 1ull), upper = has & ~((2ull << lane) - 1ull);
-                uint32_t pv = GT_NONE, nx = GT_NONE;
-                if (lower) { const uint32_t w = 63u - (uint32_t) __clzll((long long) lower); pv = w * 64u + 63u - (uint32_t) __clzll((long long) s_mask[w]); }
-                if (upper) { const uint32_t w = (uint32_t) __ffsll((long long) upper) - 1u; nx = w * 64u + (uint32_t) __ffsll((long long) s_mask[w]) - 1u; }
-                s_prevw[lane] = pv; s_nextw[lane] = nx;
-            }
-            if (PASS == 0 && lane == 0) {
-                uint32_t fh = GT_NONE, lh = GT_NONE;
-                if (has) {
-                    const uint32_t wf = (uint32_t) __ffsll((long long) has) - 1u, wl = 63u - (uint32_t) __clzll((long long) has);
-                    fh = t0 + wf * 64u + (uint32_t) __ffsll((long long) s_mask[wf]) - 1u;
-                    lh = t0 + wl * 64u + 63u - (uint32_t) __clzll((long long) s_mask[wl]);
-                }
-                a.th_first[tile] = fh; a.th_last[tile] = lh;
-            }
-        } else if (wave == 1) {                          // head of the group that runs into this tile
-            uint32_t before = t0;
-            if (!(s_mask[0] & 1ull)) {
-                if constexpr (PASS == 0) before = find_head_back(a.post, t0 - 1, lane);      // (t0 > 0: record 0 is a head)
-                else {
-                    before = 0;
-                    for (uint32_t hi = tile; hi > 0;) {  // last head of the tiles before, 64 tiles per step
-                        const uint32_t base = hi >= PDL_WAVE ? hi - PDL_WAVE : 0, idx = base + lane;
-                        const uint32_t v = idx < hi ? a.th_last[idx] : GT_NONE;
-                        const unsigned long long m = __ballot(v != GT_NONE);
-                        if (m) { before = (uint32_t) __shfl((int) v, 63 - __clzll((long long) m), PDL_WAVE); break; }
-                        hi = base;
-                    }
-                }
-            }
-            if (lane == 0) s_before = before;
-        } else if (wave == 2) {                          // end of the group that runs out of this tile
-            const uint32_t t1 = min(t0 + GT_TILE, n);
-            uint32_t after = n;
-            if constexpr (PASS == 0) after = find_head_fwd(a.post, t1, n, lane);
+        unsigned long long m[GW_ROUNDS];
+#pragma unroll
+        for (int j = 0; j < GW_ROUNDS; j++) m[j] = __ballot(t0 + j * PDL_WAVE + lane < n && (po[j].y >> 31));
+        // head of the group that runs into the tile
+        uint32_t before = last_head;
+        if (before == GT_NONE && !(m[0] & 1ull)) {       // (uniform) first tile of the wave's run and it starts inside a group
+            if constexpr (PASS == 0) before = find_head_back(a.post, t0 - 1, lane);      // (t0 > 0: record 0 is a head)
             else {
+                before = 0;
+                for (uint32_t hi = tile; hi > 0;) {      // last head of the tiles before, 64 tiles per step
+                    const uint32_t base = hi >= PDL_WAVE ? hi - PDL_WAVE : 0, idx = base + lane;
+                    const uint32_t v = idx < hi ? a.th_last[idx] : GT_NONE;
+                    const unsigned long long hm = __ballot(v != GT_NONE);
+                    if (hm) { before = (uint32_t) __shfl((int) v, 63 - __clzll((long long) hm), PDL_WAVE); break; }
+                    hi = base;
+                }
+            }
+        }
+        // end of the group that runs out of the tile
+        uint32_t after;
+        {
+            const unsigned long long pm = __ballot(peek != 0);
+            if (pm) after = t1 + (uint32_t) __ffsll((long long) pm) - 1u;
+            else if (t1 + PDL_WAVE >= n && may_peek) after = n;
+            else if constexpr (PASS == 0) after = find_head_fwd(a.post, t1 + PDL_WAVE, n, lane);
+            else {
+                after = n;
                 for (uint32_t lo = tile + 1; lo < tiles; lo += PDL_WAVE) {
                     const uint32_t idx = lo + lane;
                     const uint32_t v = idx < tiles ? a.th_first[idx] : GT_NONE;
-                    const unsigned long long m = __ballot(v != GT_NONE);
-                    if (m) { after = (uint32_t) __shfl((int) v, __ffsll((long long) m) - 1, PDL_WAVE); break; }
+                    const unsigned long long hm = __ballot(v != GT_NONE);
+                    if (hm) { after = (uint32_t) __shfl((int) v, __ffsll((long long) hm) - 1, PDL_WAVE); break; }
                 }
             }
-            if (lane == 0) s_after = after;
         }
-        __syncthreads();
-        const uint32_t before = s_before, after = s_after;
-        bool has_range[GT_ITEMS];
-        uint32_t gsv[GT_ITEMS], gev[GT_ITEMS];
-        unsigned long long rb[GT_ITEMS];
+        before = (uint32_t) __builtin_amdgcn_readfirstlane((int) before);        // (uniform by construction: keep them in scalar registers)
+        after = (uint32_t) __builtin_amdgcn_readfirstlane((int) after);
+        // first head in the rounds after round j (scalar scan from the back)
+        uint32_t nextr[GW_ROUNDS];
+        uint32_t nx = after, first_in_tile = GT_NONE;
 #pragma unroll
-        for (int j = 0; j < GT_ITEMS; j++) {
-            const uint32_t li = j * GT_THREADS + tid, u = t0 + li;
-            const uint32_t w = li >> 6, b = li & 63u;
-            const unsigned long long m = s_mask[w];
-            const unsigned long long at_or_below = m & ((2ull << b) - 1ull), above = m & ~((2ull << b) - 1ull);
-            uint32_t gs, ge;
-            if (at_or_below) gs = t0 + w * 64u + 63u - (uint32_t) __clzll((long long) at_or_below);
-            else { const uint32_t pv = s_prevw[w]; gs = pv != GT_NONE ? t0 + pv : before; }
-            if (above) ge = t0 + w * 64u + (uint32_t) __ffsll((long long) above) - 1u;
-            else { const uint32_t nx = s_nextw[w]; ge = nx != GT_NONE ? t0 + nx : after; }
+        for (int j = GW_ROUNDS - 1; j >= 0; j--) {
+            nextr[j] = nx;
+            if (m[j]) { nx = t0 + j * PDL_WAVE + (uint32_t) __ffsll((long long) m[j]) - 1u; first_in_tile = nx; }
+        }
+        uint32_t pr = before, cnt_tile = 0;              // (uniform) last head before the current round; ranges so far in the tile
+        const uint32_t tile_prefix = PASS == 1 ? chunk_prefix + a.tile_sums[tile] : 0u;
+#pragma unroll
+        for (int j = 0; j < GW_ROUNDS; j++) {
+            const uint32_t u = t0 + j * PDL_WAVE + lane;
+            const unsigned long long at_or_below = m[j] & le_mask, above = m[j] & ~le_mask;
+            const uint32_t gs = at_or_below ? t0 + j * PDL_WAVE + 63u - (uint32_t) __clzll((long long) at_or_below) : pr;
+            const uint32_t ge = above ? t0 + j * PDL_WAVE + (uint32_t) __ffsll((long long) above) - 1u : nextr[j];
             const bool live = u < n;
             const bool shared = live && ge - gs >= 2;
             bool r = shared;
             if constexpr (MODE == 1 || MODE == 2) r = r && u + 1 < ge;           // the last member of a group has nothing above it
-            if constexpr (MODE == 0 || MODE == 2) r = r && a.in_shard[po[j].x];
+            if constexpr (MODE == 0 || MODE == 2) r = r && ((ins >> j) & 1u);
             if constexpr (MODE == 3) r = false;
-            has_range[j] = r; gsv[j] = gs; gev[j] = ge;
-            rb[j] = __ballot(r);
+            const unsigned long long rb = __ballot(r);
             if constexpr (PASS == 0) {
                 n_rec += shared; n_grp += shared && u == gs;
                 if constexpr (RECORD_COSTS) { if (shared) atomicAdd(&a.cost[po[j].x], (unsigned long long) (ge - gs)); }
@@ -560,54 +572,49 @@ __global__ __launch_bounds__(GT_THREADS) void k_group_tiles(GroupTileArgs a) {
                         else { atomicAdd(&a.g_full[gen], full); if (up) atomicAdd(&a.g_upper[gen], up); }
                     }
                 }
-            }
-            if (lane == 0) s_cnt[j * (GT_THREADS / PDL_WAVE) + wave] = (uint32_t) __popcll(rb[j]);
-        }
-        __syncthreads();
-        if (wave == 0) {                                 // exclusive prefix of the 32 (round, wave) counts = record order
-            const uint32_t v = lane < GT_WORDS ? s_cnt[lane] : 0u;
-            const uint32_t inc = wave_inclusive_scan_u32(v);
-            if (lane < GT_WORDS) s_cnt[lane] = inc - v;
-            if (PASS == 0 && lane == GT_WORDS - 1) a.tile_sums[tile] = inc;
-        }
-        if constexpr (PASS == 1) {
-            __syncthreads();
-            const uint32_t tile_prefix = a.tile_sums[tile];
-#pragma unroll
-            for (int j = 0; j < GT_ITEMS; j++) {
-                const uint32_t u = t0 + j * GT_THREADS + tid;
-                if (u >= n) continue;
+            } else if (live) {
                 const uint32_t cnt = po[j].y & ~HEAD_BIT;
                 if (po[j].y >> 31) a.post[u].y = cnt;                              // the bit has done its job
-                const uint32_t gs = gsv[j], ge = gev[j];
-                if (has_range[j]) {
-                    const uint32_t at = tile_prefix + s_cnt[j * (GT_THREADS / PDL_WAVE) + wave] + (uint32_t) __popcll(rb[j] & ((1ull << lane) - 1ull));
+                if (r) {
+                    const uint32_t at = tile_prefix + cnt_tile + (uint32_t) __popcll(rb & lt_mask);
                     const uint32_t start = MODE == 0 ? gs : u + 1;
                     a.key2[at] = po[j].x;
                     a.tuples[at] = make_uint4(start, ge - start, cnt, ge - gs);     // {first posting, postings, own count, group size}
                 } else if (MODE == 1 || MODE == 2) {
-                    if (ge - gs >= 2 && u + 1 == ge && (MODE == 1 || a.in_shard[po[j].x]))
+                    if (ge - gs >= 2 && u + 1 == ge && ((ins >> j) & 1u))
                         atomicAdd(&a.cost[po[j].x], (unsigned long long) (ge - gs));
                 }
             }
+            cnt_tile += (uint32_t) __popcll(rb);
+            if (m[j]) pr = t0 + j * PDL_WAVE + 63u - (uint32_t) __clzll((long long) m[j]);
         }
+        if constexpr (PASS == 0) {
+            if (lane == 0) { a.tile_sums[tile] = running; a.th_first[tile] = first_in_tile; a.th_last[tile] = first_in_tile != GT_NONE ? pr : GT_NONE; }
+            running += cnt_tile;
+        }
+        last_head = pr;
     }
     if constexpr (PASS == 0) {
+        if (lane == 0) a.chunk_sums[gw] = running;
 #pragma unroll
         for (int d = PDL_WAVE / 2; d > 0; d >>= 1) { n_rec += __shfl_xor(n_rec, d, PDL_WAVE); n_grp += __shfl_xor(n_grp, d, PDL_WAVE); }
-        __syncthreads();
-        if (tid < 2) s_red[tid] = 0;
-        __syncthreads();
         if (lane == 0) { atomicAdd(&s_red[0], n_rec); atomicAdd(&s_red[1], n_grp); }
         __syncthreads();
         if (tid < 2 && s_red[tid]) atomicAdd(&a.counters[tid], (unsigned long long) s_red[tid]);
         if constexpr (GENOMES) {
-            if (lds_table) for (uint32_t i = tid; i < a.n_genomes; i += GT_THREADS) {
+            if (lds_table) for (uint32_t i = tid; i < a.n_genomes; i += GW_THREADS) {
                 if (s_full[i]) atomicAdd(&a.g_full[i], s_full[i]);
                 if (s_upper[i]) atomicAdd(&a.g_upper[i], s_upper[i]);
             }
         }
     }
+}
+
+// in_shard[gene] = the gene's genome belongs to this rank (multi-GPU: from the genome deal, without a host round trip)
+__global__ __launch_bounds__(256) void k_genes_of_rank(const uint32_t *__restrict__ genome_of, const uint32_t *__restrict__ owner, uint32_t rank,
+                                                       uint32_t n_seq, uint8_t *__restrict__ in_shard) {
+    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+    if (s < n_seq) in_shard[s] = owner[genome_of[s]] == rank ? 1 : 0;
 }
 
 // Also adds up total_visited (library.cpp:327) = the group sizes over a gene's ranges: the list is gene-sorted, so a
@@ -655,19 +662,35 @@ __global__ __launch_bounds__(256) void k_seq_offsets(const uint32_t *__restrict_
 }
 
 // K-cost: per-genome cost (library.cpp:535-538); the total is their sum (library.cpp:337-349).
-// Genes of a genome are usually adjacent, so a wave first tries to add up as one.
+// Genes of a genome are usually adjacent, so a wave first tries to add up as one.  The three dataset-wide values
+// (sum / max / min of kseq_lengths) are kept per lane over a grid-stride loop and leave the workgroup as ONE atomic each:
+// same-address device atomics serialise at ~10-50 ns apiece, a wave's worth per 64 genes took longer than the sums.
 __global__ __launch_bounds__(256) void k_genome_cost(const unsigned long long *__restrict__ cost, const uint32_t *__restrict__ kseq_len,
                                                      const uint32_t *__restrict__ genome_of, uint32_t n_seq,
                                                      unsigned long long *__restrict__ genome_cost, unsigned long long *__restrict__ sum_kseq,
                                                      unsigned long long *__restrict__ max_kseq, unsigned long long *__restrict__ min_kseq) {
-    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
-    const bool live = s < n_seq;
-    unsigned long long c = live ? cost[s] : 0ull;
-    unsigned long long kl = live ? (unsigned long long) kseq_len[s] : 0ull;
-    const uint32_t g = live ? genome_of[s] : 0xffffffffu;
-    const uint32_t g0 = __shfl(g, 0, PDL_WAVE);
-    const bool uniform = __all(g == g0 || !live);
-    unsigned long long ksum = kl, kmax = kl, csum = c, kmin = kl ? kl : ~0ull;
+    __shared__ unsigned long long s_sum, s_max, s_min;
+    if (threadIdx.x == 0) { s_sum = 0; s_max = 0; s_min = ~0ull; }
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & (PDL_WAVE - 1);
+    unsigned long long ksum = 0, kmax = 0, kmin = ~0ull;
+    for (uint32_t s0 = blockIdx.x * 256; s0 < n_seq; s0 += gridDim.x * 256) {
+        const uint32_t s = s0 + threadIdx.x;
+        const bool live = s < n_seq;
+        unsigned long long c = live ? cost[s] : 0ull;
+        const unsigned long long kl = live ? (unsigned long long) kseq_len[s] : 0ull;
+        const uint32_t g = live ? genome_of[s] : 0xffffffffu;
+        ksum += kl; kmax = kl > kmax ? kl : kmax; if (kl && kl < kmin) kmin = kl;
+        const uint32_t g0 = __shfl(g, 0, PDL_WAVE);
+        if (__all(g == g0 || !live)) {
+            unsigned long long csum = c;
+#pragma unroll
+            for (int d = PDL_WAVE / 2; d > 0; d >>= 1) csum += __shfl_down(csum, d, PDL_WAVE);
+            if (lane == 0 && csum && g0 != 0xffffffffu) atomicAdd(&genome_cost[g0], csum);
+        } else if (live && c) {
+            atomicAdd(&genome_cost[g], c);
+        }
+    }
 #pragma unroll
     for (int d = PDL_WAVE / 2; d > 0; d >>= 1) {
         ksum += __shfl_down(ksum, d, PDL_WAVE);
@@ -675,15 +698,10 @@ __global__ __launch_bounds__(256) void k_genome_cost(const unsigned long long *_
         kmax = o > kmax ? o : kmax;
         o = __shfl_down(kmin, d, PDL_WAVE);
         kmin = o < kmin ? o : kmin;
-        csum += __shfl_down(csum, d, PDL_WAVE);
     }
-    const uint32_t lane = threadIdx.x & (PDL_WAVE - 1);
-    if (lane == 0 && ksum) { atomicAdd(sum_kseq, ksum); atomicMax(max_kseq, kmax); atomicMax(min_kseq, ~kmin); }   // min kept as a max of complements: zero-initialised like the rest
-    if (uniform) {
-        if (lane == 0 && csum && g0 != 0xffffffffu) atomicAdd(&genome_cost[g0], csum);
-    } else if (live && c) {
-        atomicAdd(&genome_cost[g], c);
-    }
+    if (lane == 0) { atomicAdd(&s_sum, ksum); atomicMax(&s_max, kmax); atomicMin(&s_min, kmin); }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_sum) { atomicAdd(sum_kseq, s_sum); atomicMax(max_kseq, s_max); atomicMax(min_kseq, ~s_min); }   // min kept as a max of complements: zero-initialised like the rest
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -780,10 +798,11 @@ static void stage_sort_and_dedup(pdl_ctx *c, KeyT *keys_in, KeyT *keys_out, uint
                    RecScatter<KeyT>{skeys, svals, m, c->recpos.as<uint32_t>(), c->post.as<uint2>()}, d_scal + 0);
 }
 
-// Launch helper of k_group_tiles: persistent workgroups over the tiles.
-template <int PASS, int MODE, bool GENOMES, bool RECORD_COSTS>
-static void launch_group_tiles(pdl_ctx *c, const GroupTileArgs &a) {
-    const uint64_t tiles = (a.n_bound + GT_TILE - 1) / GT_TILE;
+// Launch helpers of k_group_waves.  group_tiles_plan sizes the grid (every wave owns a run of consecutive tiles) and the
+// scratch: tile_sums[tiles] | th_first[tiles] | th_last[tiles] | chunk_sums[waves].  Returns the number of workgroups.
+static uint32_t group_tiles_plan(pdl_ctx *c, GroupTileArgs &a) {
+    const uint64_t tiles = (a.n_bound + GW_TILE - 1) / GW_TILE;
+    if (tiles > 0x7fffffffull) PDL_FAIL(PDL_ERR_UNSUPPORTED, "dictionary of %llu records exceeds the grid limit", (unsigned long long) a.n_bound);
     int cus = c->cus;
     if (cus <= 0) {
         cus = 256;
@@ -791,37 +810,37 @@ static void launch_group_tiles(pdl_ctx *c, const GroupTileArgs &a) {
         if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) cus = prop.multiProcessorCount;
         c->cus = cus;
     }
-    const uint32_t grid = (uint32_t) std::max<uint64_t>(1, std::min<uint64_t>(tiles, (uint64_t) cus * (GENOMES ? 2 : 8)));
-    hipLaunchKernelGGL((k_group_tiles<PASS, MODE, GENOMES, RECORD_COSTS>), dim3(grid), dim3(GT_THREADS), 0, c->stream, a);
+    const uint64_t want_waves = std::max<uint64_t>(1, std::min<uint64_t>(tiles, (uint64_t) cus * 8 * GW_WAVES));
+    a.tiles_per_chunk = (uint32_t) std::max<uint64_t>(1, (tiles + want_waves - 1) / want_waves);
+    const uint64_t waves = std::max<uint64_t>(1, (tiles + a.tiles_per_chunk - 1) / a.tiles_per_chunk);
+    const uint32_t grid = (uint32_t) ((waves + GW_WAVES - 1) / GW_WAVES);
+    c->scan_tmp.alloc(((size_t) tiles * 3 + (size_t) grid * GW_WAVES + 1) * sizeof(uint32_t));
+    a.tile_sums = c->scan_tmp.as<uint32_t>(); a.th_first = a.tile_sums + tiles; a.th_last = a.th_first + tiles; a.chunk_sums = a.th_last + tiles;
+    return grid;
+}
+template <int PASS, int MODE, bool GENOMES, bool RECORD_COSTS>
+static void launch_group_tiles(pdl_ctx *c, const GroupTileArgs &a, uint32_t grid) {
+    const size_t dyn = GENOMES && a.n_genomes <= COST_LDS_GENOMES ? 2 * (size_t) a.n_genomes * sizeof(uint64_t) : 0;
+    hipLaunchKernelGGL((k_group_waves<PASS, MODE, GENOMES, RECORD_COSTS>), dim3(grid), dim3(GW_THREADS), dyn, c->stream, a);
     PDL_HIP(hipGetLastError());
 }
 
 // K-groups + K-ranges + K-cost over the dictionary (postings with head bits; `bound` records at most, the count is at
 // d_scal[0]).  mode 0: whole groups for the shard's genes | 1: upper ranges, every gene | 2: upper ranges, the shard's genes.
-// genomes_pass: the COUNT pass also adds up every genome's lookups (multi-GPU: behind the control block's K-cost words).
-static void stage_ranges_and_costs(pdl_ctx *c, uint64_t bound, int mode, bool only_complexity, bool genomes_pass) {
+static void stage_ranges_and_costs(pdl_ctx *c, uint64_t bound, int mode, bool only_complexity) {
     hipStream_t st = c->stream;
     uint64_t *d_scal = c->scalars.as<uint64_t>();
     const uint64_t *d_u = d_scal + 0;
     uint2 *post = pdl_postings(c);
-    const uint64_t tiles = (bound + GT_TILE - 1) / GT_TILE;
-    if (tiles > 0x7fffffffull) PDL_FAIL(PDL_ERR_UNSUPPORTED, "dictionary of %llu records exceeds the grid limit", (unsigned long long) bound);
-    c->scan_tmp.alloc((size_t) tiles * 3 * sizeof(uint32_t));
     GroupTileArgs ga{};
     ga.post = post; ga.n_bound = bound; ga.d_n = d_u;
-    ga.tile_sums = c->scan_tmp.as<uint32_t>(); ga.th_first = ga.tile_sums + tiles; ga.th_last = ga.th_first + tiles;
+    const uint32_t grid = group_tiles_plan(c, ga);
     ga.cost = c->cost.as<unsigned long long>();
     ga.counters = reinterpret_cast<unsigned long long *>(d_scal + 10);
     ga.genome_of = c->d_gen; ga.n_genomes = c->G;
-    ga.g_full = reinterpret_cast<unsigned long long *>(d_scal + PDL_CTL_GCOST) + c->G;
-    if (genomes_pass) {              // (the lookups above the diagonal are added up as well; only the deal's own pass reads them)
-        c->scratch2.alloc(std::max<size_t>(c->scratch2.bytes, (size_t) c->G * sizeof(uint64_t)));
-        PDL_HIP(hipMemsetAsync(c->scratch2.p, 0, (size_t) c->G * sizeof(uint64_t), st));
-        ga.g_upper = c->scratch2.as<unsigned long long>();
-    }
     hipLaunchKernelGGL(k_fold_last_record, dim3(1), dim3(1024), 0, st, post, c->post_ext ? (uint32_t *) nullptr : c->recpos.as<uint32_t>(), d_u);
     if (only_complexity) {                   // (cost[] was zeroed by K-len's apply, the counters with the control block)
-        launch_group_tiles<0, 3, false, true>(c, ga);
+        launch_group_tiles<0, 3, false, true>(c, ga, grid);
     } else {
         ev_begin(c, EV_SORT2);
         // scratch layout: tuples uint4[bound] | v2a u32[bound] | k2b u32[bound] | v2b u32[bound]; key2 lives in vals_a (free after sort 1)
@@ -832,7 +851,9 @@ static void stage_ranges_and_costs(pdl_ctx *c, uint64_t bound, int mode, bool on
         uint32_t *v2a = reinterpret_cast<uint32_t *>(tuples + bound);
         uint32_t *k2b = v2a + bound;
         uint32_t *v2b = k2b + bound;
-        if (mode != 1) {                    // only the genes this context scores need range lists
+        if (mode != 1 && c->dist) {         // multi-GPU: the deal is on the device already (pdl_run_dist_finish)
+            ga.in_shard = c->seq_in_shard.as<uint8_t>();
+        } else if (mode != 1) {             // only the genes this context scores need range lists
             std::vector<uint8_t> &h = c->h_seq_in_shard;   // lives in the context: the copy below needs no synchronisation
             h.assign((size_t) c->N, 0);
             std::vector<uint8_t> gsel((size_t) c->G, 0);
@@ -844,13 +865,13 @@ static void stage_ranges_and_costs(pdl_ctx *c, uint64_t bound, int mode, bool on
         }
         ga.key2 = k2a; ga.tuples = tuples;
         const uint64_t *d_us = d_scal + 2;       // ranges built = the total of the tile counts
-        if (mode == 1) launch_group_tiles<0, 1, false, false>(c, ga);
-        else if (mode == 2) { if (genomes_pass) launch_group_tiles<0, 2, true, false>(c, ga); else launch_group_tiles<0, 2, false, false>(c, ga); }
-        else launch_group_tiles<0, 0, false, false>(c, ga);
-        hipLaunchKernelGGL(k_scan_tile_scan, dim3(1), dim3(1024), 0, st, ga.tile_sums, (uint32_t) tiles, d_scal + 2, (uint64_t *) nullptr);
-        if (mode == 1) launch_group_tiles<1, 1, false, false>(c, ga);
-        else if (mode == 2) launch_group_tiles<1, 2, false, false>(c, ga);
-        else launch_group_tiles<1, 0, false, false>(c, ga);
+        if (mode == 1) launch_group_tiles<0, 1, false, false>(c, ga, grid);
+        else if (mode == 2) launch_group_tiles<0, 2, false, false>(c, ga, grid);
+        else launch_group_tiles<0, 0, false, false>(c, ga, grid);
+        hipLaunchKernelGGL(k_scan_tile_scan, dim3(1), dim3(1024), 0, st, ga.chunk_sums, grid * GW_WAVES, d_scal + 2, (uint64_t *) nullptr);
+        if (mode == 1) launch_group_tiles<1, 1, false, false>(c, ga, grid);
+        else if (mode == 2) launch_group_tiles<1, 2, false, false>(c, ga, grid);
+        else launch_group_tiles<1, 0, false, false>(c, ga, grid);
         c->upper_only = mode != 0;
         const uint32_t seq_bits = std::max<uint32_t>(1, bit_length64(c->N ? c->N - 1 : 0));
         // One GPU: the range count stays on the device, the kernels behind it are sized for the bound.  Multi-GPU: a rank
@@ -858,6 +879,7 @@ static void stage_ranges_and_costs(pdl_ctx *c, uint64_t bound, int mode, bool on
         uint64_t n_sort = bound;
         const uint64_t *d_sort_n = d_us;
         if (c->dist) {
+            if (!c->tasks_ready) pdl_prepare_tasks(c);       // host work + small uploads while the device runs the two passes
             PinRead rd(c);
             const uint64_t *pn = rd.add<uint64_t>(d_us, 1);
             rd.sync();
@@ -878,7 +900,7 @@ static void stage_ranges_and_costs(pdl_ctx *c, uint64_t bound, int mode, bool on
 
     // K-cost
     unsigned long long *d_gcost = reinterpret_cast<unsigned long long *>(d_scal + PDL_CTL_GCOST);
-    hipLaunchKernelGGL(k_genome_cost, dim3((c->N + 255) / 256), dim3(256), 0, st, c->cost.as<unsigned long long>(),
+    hipLaunchKernelGGL(k_genome_cost, dim3(std::min<uint32_t>((c->N + 255) / 256, 128)), dim3(256), 0, st, c->cost.as<unsigned long long>(),
                        c->kseq_len.as<uint32_t>(), c->d_gen, c->N, d_gcost,
                        reinterpret_cast<unsigned long long *>(d_scal + 4), reinterpret_cast<unsigned long long *>(d_scal + 7),
                        reinterpret_cast<unsigned long long *>(d_scal + 8));
@@ -887,11 +909,9 @@ static void stage_ranges_and_costs(pdl_ctx *c, uint64_t bound, int mode, bool on
     uint64_t tail[12] = {0};
     {
         PinRead rd(c);                       // one copy: the whole control block
-        const uint64_t *pt = rd.add<uint64_t>(d_scal, PDL_CTL_GCOST + 2 * (size_t) c->G);
+        const uint64_t *pt = rd.add<uint64_t>(d_scal, PDL_CTL_GCOST + (size_t) c->G);
         rd.sync();
-        // one GPU / a plain shard: per-genome costs from the per-gene ones; multi-GPU: every genome's cost from the COUNT pass
-        const uint64_t *pg = pt + PDL_CTL_GCOST + (genomes_pass ? c->G : 0);
-        c->h_genome_cost.assign(pg, pg + c->G);
+        c->h_genome_cost.assign(pt + PDL_CTL_GCOST, pt + PDL_CTL_GCOST + c->G);     // (a shard, one rank of several: its own genomes only)
         memcpy(tail, pt, sizeof(tail));
     }
     c->U = tail[0];
@@ -917,7 +937,7 @@ static void dictionary_pipeline(pdl_ctx *c, bool only_complexity) {
     if (!only_complexity) pdl_prepare_tasks(c);     // host work + small uploads while the device sorts
     // U (records) and the range count stay on the device until the end of the build: everything below is sized and
     // launched for the bound M and reads the counts there — no host round trip in the middle of the pipeline
-    stage_ranges_and_costs(c, M, c->dict_shard.empty() ? 1 : 0, only_complexity, false);
+    stage_ranges_and_costs(c, M, c->dict_shard.empty() ? 1 : 0, only_complexity);
 }
 
 void pdl_run_preprocess(pdl_ctx *c, int kvalue, bool only_complexity) {
@@ -989,16 +1009,14 @@ static void dist_slice_pipeline(pdl_ctx *c) {
         stage_sort_and_dedup<KeyT>(c, keys_in, keys_out, vals_in, vals_out, m_own);
         // every genome's lookups above the diagonal inside this run (groups never straddle runs): summed over the ranks
         // they are the weights of the genome deal (the fold of the globally last record is not in them: they only balance)
-        const uint64_t tiles = (m_own + GT_TILE - 1) / GT_TILE;
-        c->scan_tmp.alloc((size_t) tiles * 3 * sizeof(uint32_t));
         GroupTileArgs ga{};
         ga.post = c->post.as<uint2>(); ga.n_bound = m_own; ga.d_n = d_scal + 0;
-        ga.tile_sums = c->scan_tmp.as<uint32_t>(); ga.th_first = ga.tile_sums + tiles; ga.th_last = ga.th_first + tiles;
+        const uint32_t grid = group_tiles_plan(c, ga);
         ga.counters = reinterpret_cast<unsigned long long *>(d_scal + 12);      // (scratch words: the real counters come from the finish)
         ga.genome_of = c->d_gen; ga.n_genomes = c->G;
         ga.g_full = reinterpret_cast<unsigned long long *>(d_scal + PDL_CTL_GCOST);             // scratch here, cleared again by the finish
         ga.g_upper = reinterpret_cast<unsigned long long *>(d_scal + PDL_CTL_GCOST) + c->G;
-        launch_group_tiles<0, 3, true, false>(c, ga);
+        launch_group_tiles<0, 3, true, false>(c, ga, grid);
         ev_end(c, EV_DICT);
     } else {
         c->post.alloc(16);
@@ -1060,8 +1078,9 @@ void pdl_run_dist_finish(pdl_ctx *c, uint64_t total, const uint64_t *weights) {
     if (!h_u) PDL_FAIL(PDL_ERR_DEVICE, "pinned scratch missing");
     h_u[0] = total;
     PDL_HIP(hipMemcpyAsync(d_scal + 0, h_u, sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    // (words 3-8 belong to K-len and stay: bad-offsets flag, kseq sums, M)
     PDL_HIP(hipMemsetAsync(d_scal + 1, 0, 2 * sizeof(uint64_t), st));
-    PDL_HIP(hipMemsetAsync(d_scal + 9, 0, 4 * sizeof(uint64_t), st));
+    PDL_HIP(hipMemsetAsync(d_scal + 9, 0, 7 * sizeof(uint64_t), st));
     PDL_HIP(hipMemsetAsync(d_scal + PDL_CTL_GCOST, 0, 2 * (size_t) c->G * sizeof(uint64_t), st));
     // genomes -> ranks by longest-processing-time on each genome's lookups above the diagonal: the caller's sum of the
     // runs' weights, or — without one — an exact pass over the gathered dictionary first
@@ -1069,19 +1088,17 @@ void pdl_run_dist_finish(pdl_ctx *c, uint64_t total, const uint64_t *weights) {
     if (weights) {
         c->h_upper_cost.assign(weights, weights + c->G);
     } else {
-        const uint64_t tiles = (total + GT_TILE - 1) / GT_TILE;
-        c->scan_tmp.alloc((size_t) tiles * 3 * sizeof(uint32_t));
         c->scratch2.alloc(std::max<size_t>(c->scratch2.bytes, ((size_t) c->G + 2) * sizeof(uint64_t)));
         PDL_HIP(hipMemsetAsync(c->scratch2.p, 0, ((size_t) c->G + 2) * sizeof(uint64_t), st));
         GroupTileArgs ga{};
         ga.post = c->post_ext; ga.n_bound = total; ga.d_n = nullptr;
-        ga.tile_sums = c->scan_tmp.as<uint32_t>(); ga.th_first = ga.tile_sums + tiles; ga.th_last = ga.th_first + tiles;
+        const uint32_t grid = group_tiles_plan(c, ga);
         ga.counters = c->scratch2.as<unsigned long long>() + c->G;
         ga.genome_of = c->d_gen; ga.n_genomes = c->G;
         ga.g_upper = c->scratch2.as<unsigned long long>();
         ga.g_full = reinterpret_cast<unsigned long long *>(d_scal + PDL_CTL_GCOST);       // (scratch: the K-cost words are cleared below)
         // (the fold of the last record is not applied yet: as with the callers' weights, these numbers only balance)
-        launch_group_tiles<0, 3, true, false>(c, ga);
+        launch_group_tiles<0, 3, true, false>(c, ga, grid);
         {
             PinRead rd(c);
             const uint64_t *pu = rd.add<uint64_t>(ga.g_upper, c->G);
@@ -1095,9 +1112,13 @@ void pdl_run_dist_finish(pdl_ctx *c, uint64_t total, const uint64_t *weights) {
     for (uint32_t g = 0; g < c->G; g++) if (c->h_owner[g] == c->rank) c->shard.push_back(g);
     c->shard_set = true;
     c->dict_shard = c->shard;
-    c->tasks_ready = false;
-    pdl_prepare_tasks(c);
-    stage_ranges_and_costs(c, total, 2, false, true);
+    c->tasks_ready = false;                 // (the task layout is prepared inside, behind the launches of the two passes)
+    c->owner_of_genome.alloc((size_t) c->G * 4);
+    PDL_HIP(hipMemcpyAsync(c->owner_of_genome.p, c->h_owner.data(), (size_t) c->G * 4, hipMemcpyHostToDevice, st));
+    c->seq_in_shard.alloc(c->N);
+    hipLaunchKernelGGL(k_genes_of_rank, dim3((c->N + 255) / 256), dim3(256), 0, st, c->d_gen, c->owner_of_genome.as<uint32_t>(), c->rank, c->N,
+                       c->seq_in_shard.as<uint8_t>());
+    stage_ranges_and_costs(c, total, 2, false);
     ev_end(c, EV_DIST_FINISH);
     ev_end(c, EV_PRE_TOTAL);
     PDL_HIP(hipStreamSynchronize(st));

@@ -1372,6 +1372,7 @@ void pdl_run_dist_score_begin(pdl_ctx *c) {
             rd.sync();
             memcpy(h_tot, pt, (W + 1) * 4); memcpy(h_ctr, pc, sizeof(h_ctr));
         }
+        c->glb_clean = true;                 // (k_join_hbm has run to its end and left its tables zeroed)
         if (h_ctr[6]) PDL_FAIL(PDL_ERR_DEVICE, "join: %u internal consistency violations", h_ctr[6]);
         unsigned long long z;
         memcpy(&z, &h_ctr[4], sizeof(z));

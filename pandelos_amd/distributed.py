@@ -203,6 +203,10 @@ class DistributedPangenes:
         self.exchange_s["cells"] = time.perf_counter() - t0
         nat.dist_score_finish(recv.data_ptr(), n_in, keepalive=recv)
 
+    def total_cost(self) -> int:
+        """"Total cost: P lookups" (library.cpp:349): every rank holds the costs of its own genomes; their sum over the ranks."""
+        return int(round(all_reduce_sum([float(self.nat.cost.total_cost)], device=self.dev if self.on_device else None)[0]))
+
     def my_genomes(self) -> List[int]:
         owner = self.nat.dist_genome_owner()
         return [int(g) for g in np.nonzero(owner == self.rank)[0]]
@@ -246,7 +250,12 @@ class LocalRanks:
         self.owner = self.ranks[0].dist_genome_owner()
         for n in self.ranks[1:]:
             assert np.array_equal(n.dist_genome_owner(), self.owner), "ranks disagree on the genome deal"
+        # a rank reports the lookups of ITS genomes ("Genome g cost", library.cpp:535-538); "Total cost" is their sum over the ranks
+        self.total_cost = sum(int(n.cost.total_cost) for n in self.ranks)
         return self.ranks[0].cost
+
+    def genome_cost(self, genome: int) -> int:
+        return self.ranks[int(self.owner[genome])].genome_cost(genome)
 
     def score_all(self):
         import torch

@@ -41,11 +41,11 @@ def _local(world, res, off, gen, k, flags=0, exchange_weights=True):
 def test_ranks_together_reproduce_the_fixture(name, world):
     res, off, gen, k, fx = H.load_small(name)
     lr, cost = _local(world, res, off, gen, k)
-    assert cost.total_cost == int(fx["total_cost"]) and (cost.sequences, cost.genomes) == (int(fx["sequences"]), int(fx["genomes"]))
+    assert lr.total_cost == int(fx["total_cost"]) and (cost.sequences, cost.genomes) == (int(fx["sequences"]), int(fx["genomes"]))
     assert sum(lr.run_records) == cost.dictionary_records
-    for n in lr.ranks:                                   # every rank knows every genome's cost (library.cpp:535-538)
-        assert [n.genome_cost(g) for g in range(cost.genomes)] == [int(x) for x in fx["genome_cost"]]
-        assert (n.cost.groups, n.cost.shared_records) == (cost.groups, cost.shared_records)
+    assert [lr.genome_cost(g) for g in range(cost.genomes)] == [int(x) for x in fx["genome_cost"]]     # each from its owner (library.cpp:535-538)
+    for n in lr.ranks:                                   # counters over the whole dictionary: the same everywhere
+        assert (n.cost.groups, n.cost.shared_records, n.cost.dictionary_records) == (cost.groups, cost.shared_records, cost.dictionary_records)
     lr.score_all()
     assert all(int(x) < world for x in lr.owner)
     H.assert_scores_equal_fixture(lambda g: lr.generate_scores_part(g).as_dict(), fx, cost.genomes, f"{name} W={world}")
@@ -64,13 +64,13 @@ def test_ranks_together_reproduce_the_fixture(name, world):
 def test_ranks_together_reproduce_the_reference_digest(world, weights):
     res, off, gen, k, d = H.load_large("synth_16x1000x300_k5")
     lr, cost = _local(world, res, off, gen, k, exchange_weights=weights)
-    assert cost.total_cost == d["total_cost"]
+    assert lr.total_cost == d["total_cost"]
     lr.score_all()
     H.assert_scores_match_digest(lambda g: lr.generate_scores_part(g).as_dict(), d, f"W={world}")
     # the deal balances what the join walks (lookups above the diagonal), within one genome's worth
     walked = [n.timings()["walked_lookups"] for n in lr.ranks]
     # (the deal's weights leave out the fold of the globally last record, library.cpp:300-306: at most one group's size off)
-    assert abs(sum(walked) * 2 - (cost.total_cost - cost.shared_records)) <= 2 * cost.sequences
+    assert abs(sum(walked) * 2 - (lr.total_cost - cost.shared_records)) <= 2 * cost.sequences
     assert max(walked) - min(walked) <= max(walked) / 2
     lr.close()
 
@@ -102,7 +102,7 @@ def test_random_sets_sharded_match_the_oracle(seed):
     ora = ob.Oracle(res, off, gen, k)
     world = 2 + seed % 3
     lr, cost = _local(world, res, off, gen, k, exchange_weights=bool(seed & 4))
-    assert cost.total_cost == ora.total_cost
+    assert lr.total_cost == ora.total_cost
     lr.score_all()
     for g in range(ora.genomes):
         H.assert_scores_equal(lr.generate_scores_part(g).as_dict(), ora.scores(g), f"seed {seed} W={world} genome {g}")
@@ -128,7 +128,8 @@ def _rank_main(rank, world, port, name, out):
         res, off, gen, k, d = H.load_large(name)
         t = _device_inputs(res, off, gen)
         dp = DistributedPangenes(PangeneNative.open(), torch.device("cuda", 0), device_collectives=False)
-        cost = dp.preprocess(k, *t, len(gen), len(res))
+        dp.preprocess(k, *t, len(gen), len(res))
+        total_cost = dp.total_cost()
         dp.score_all()
         mine = dp.my_genomes()
         import hashlib
@@ -136,7 +137,7 @@ def _rank_main(rank, world, port, name, out):
         for g in mine:
             got = dp.nat.generate_scores_part(g).as_dict()
             digests[g] = (int(got["scoresCount"]), {f: hashlib.sha256(H.raw(got[f]).tobytes()).hexdigest() for f in H.FIELDS})
-        out.put((rank, int(cost.total_cost), digests))
+        out.put((rank, total_cost, digests))
     finally:
         dist.destroy_process_group()
 

@@ -104,6 +104,7 @@ class Runner:
     def __init__(self, torch, dev, stream, n_gpus, rank, on_device_collectives):
         self.torch, self.dev, self.stream = torch, dev, stream
         self.n_gpus, self.rank, self.on_dev = n_gpus, rank, on_device_collectives
+        self.options = []
 
     def load(self, gs, k):
         torch = self.torch
@@ -116,6 +117,8 @@ class Runner:
         torch.cuda.synchronize()
         # one context per rank for the whole run: every step redoes all the work, only allocations are reused
         self.nat = PangeneNative.open(stream=self.stream)
+        for name, value in self.options:
+            self.nat.set_option(name, value)
         self.dp = None
         if self.n_gpus > 1:
             from pandelos_amd.distributed import DistributedPangenes
@@ -208,6 +211,7 @@ def main():
     ap.add_argument("--no-scale-set", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=64)
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="pdl_set_option on every context (experiments)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -238,6 +242,7 @@ def main():
     coll_dev = dev if backend == "nccl" else None      # where the scalar collectives live
     stream = torch.cuda.current_stream().cuda_stream
     run = Runner(torch, dev, stream, n_gpus, rank, backend == "nccl")
+    run.options = [(o.split("=")[0], int(o.split("=")[1])) for o in args.option]
 
     # ---- workload -----------------------------------------------------------------------------------
     if args.faa:

@@ -137,6 +137,8 @@ struct pdl_ctx {
     bool shard_set = false;
     std::vector<uint32_t> dict_shard;         // genomes whose genes have range lists on the device (empty = all)
     DevBuf seq_in_shard;                      // u8 [N] gene belongs to dict_shard
+    DevBuf own_iv;                            // uint2 [intervals] the same as sorted gene-id intervals, when genomes are consecutive id ranges
+    std::vector<uint2> h_own_iv;
     std::vector<uint8_t> h_seq_in_shard;      // its host copy (kept alive for the asynchronous upload)
 
     // scoring results (device)

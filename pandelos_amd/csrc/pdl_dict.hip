@@ -437,10 +437,12 @@ __global__ __launch_bounds__(1024) void k_fold_last_record(uint2 *__restrict__ p
 struct GroupTileArgs {
     uint2 *post;
     uint64_t n_bound; const uint64_t *d_n;      // record count: on the device (at most n_bound) or n_bound itself
-    const uint8_t *in_shard;                    // MODE 0, 2: the genes that get range lists
-    uint32_t *tile_sums;                        // [tiles] COUNT: ranges in the wave's tiles before this one
-    uint32_t *chunk_sums;                       // [waves] COUNT: ranges of a wave's tiles; exclusive-scanned between the passes
-    uint32_t tiles_per_chunk;                   // a wave owns this many consecutive tiles
+    const uint8_t *in_shard;                    // MODE 0, 2: the genes that get range lists, one byte per gene ...
+    const uint2 *own_iv; uint32_t n_own_iv;     // ... or (n_own_iv > 0) as sorted, disjoint gene-id intervals [x, y): searched in LDS,
+                                                //     where a per-record byte gather would cost 64 addresses per instruction
+    uint32_t *tile_sums;                        // [tiles] COUNT: ranges of the tile; k_tile_prefix: of the tiles before it in its block of 64
+    uint32_t *chunk_sums;                       // [blocks of 64 tiles] ranges of a block; exclusive-scanned between the passes
+    uint32_t n_blocks;
     uint32_t *th_first, *th_last;               // [tiles] first / last head of a tile (GT_NONE: none), COUNT -> WRITE
     uint32_t *key2; uint4 *tuples;              // WRITE
     unsigned long long *cost;                   // per-gene total_visited (library.cpp:327): last members (WRITE), all shared records (COUNT, RECORD_COSTS)
@@ -451,19 +453,22 @@ struct GroupTileArgs {
 
 // One WAVE per tile of GW_TILE consecutive records, no LDS and no barrier on the data path: the head bits of a round of
 // 64 records are one ballot (a scalar register pair); previous / next head of a record come from bit scans of its
-// round's mask, from scalar scans over the rounds, and — for the groups that cross the tile's borders — from the
-// wave's previous tile (a wave owns consecutive tiles) and a peek at the 64 records behind the tile.  Only the first
-// tile of a wave's run looks back through memory, and only a group longer than that peek looks further ahead.
-// The ranges of a tile go to (scanned total of the waves before) + (running count of the wave) + rank inside the tile,
-// i.e. in record order.
+// round's mask, from scalar scans over the rounds, and — for the groups that cross the tile's borders — from a look at
+// the records around the tile (COUNT) or at the per-tile head positions the COUNT pass left (WRITE).
+// The ranges of a tile go to (scanned total of the 64-tile blocks before) + (tiles before it in its block) + rank
+// inside the tile, i.e. in record order.
 // MODE 0: whole groups for the genes of a shard | 1: the postings above the record, every gene | 2: those, for the genes
 // of a shard | 3: no ranges (counters / costs only).  PASS 0 = COUNT, 1 = WRITE.
 constexpr int GW_ROUNDS = 16, GW_TILE = GW_ROUNDS * PDL_WAVE, GW_THREADS = 256, GW_WAVES = GW_THREADS / PDL_WAVE;
+constexpr uint32_t GW_MAX_IV = 2048;                     // gene-id intervals of a shard held in LDS (16 KiB); more: the byte table
 template <int PASS, int MODE, bool GENOMES, bool RECORD_COSTS>
 __global__ __launch_bounds__(GW_THREADS) void k_group_waves(GroupTileArgs a) {
     __shared__ uint32_t s_red[2];
-    extern __shared__ unsigned long long s_dyn[];        // GENOMES with <= COST_LDS_GENOMES genomes: full[G] | upper[G]
+    extern __shared__ unsigned long long s_dyn[];        // GENOMES with <= COST_LDS_GENOMES genomes: full[G] | upper[G];  shard modes: intervals
     unsigned long long *s_full = s_dyn, *s_upper = s_dyn + a.n_genomes;
+    uint2 *s_iv = reinterpret_cast<uint2 *>(s_dyn);      // (GENOMES and the shard modes never come together)
+    const uint32_t n_iv = (MODE == 0 || MODE == 2) ? a.n_own_iv : 0u;
+    if constexpr (MODE == 0 || MODE == 2) { for (uint32_t i = threadIdx.x; i < n_iv; i += GW_THREADS) s_iv[i] = a.own_iv[i]; }
     const uint32_t tid = threadIdx.x, lane = tid & (PDL_WAVE - 1);
     const uint32_t gw = blockIdx.x * GW_WAVES + tid / PDL_WAVE;                  // this wave's index = its chunk of tiles
     const uint32_t n = (uint32_t) scan_count(a.n_bound, a.d_n);
@@ -473,11 +478,10 @@ __global__ __launch_bounds__(GW_THREADS) void k_group_waves(GroupTileArgs a) {
     if (tid < 2) s_red[tid] = 0;
     __syncthreads();
     const unsigned long long lt_mask = (1ull << lane) - 1ull, le_mask = (2ull << lane) - 1ull;
-    const uint32_t tile_lo = gw * a.tiles_per_chunk, tile_hi = min(tiles, tile_lo + a.tiles_per_chunk);
-    const uint32_t chunk_prefix = PASS == 1 ? a.chunk_sums[gw] : 0u;
-    uint32_t running = 0, n_rec = 0, n_grp = 0;
-    uint32_t last_head = GT_NONE;                        // (wave-uniform) last head in this wave's tiles so far
-    for (uint32_t tile = tile_lo; tile < tile_hi; tile++) {
+    uint32_t n_rec = 0, n_grp = 0;
+    // Tiles are dealt round-robin over the waves: the waves in flight read neighbouring tiles (a wave that owned a run of
+    // consecutive tiles kept every wave on its own far-apart addresses, and the pass at a quarter of the streaming rate).
+    for (uint32_t tile = gw; tile < tiles; tile += gridDim.x * GW_WAVES) {
         const uint32_t t0 = tile * GW_TILE, t1 = min(t0 + (uint32_t) GW_TILE, n);
         uint2 po[GW_ROUNDS];
 #pragma unroll
@@ -485,53 +489,82 @@ __global__ __launch_bounds__(GW_THREADS) void k_group_waves(GroupTileArgs a) {
             const uint32_t u = t0 + j * PDL_WAVE + lane;
             po[j] = a.post[u < n ? u : n - 1];
         }
-        // the 64 records behind the tile: where the group that runs out of it ends (WRITE: only inside the wave's own
-        // tiles, whose head bits it has not removed yet; beyond them the COUNT pass's per-tile heads answer)
-        const bool may_peek = PASS == 0 || tile + 1 < tile_hi;
+        // COUNT: the 64 records behind the tile say where the group that runs out of it ends.  WRITE: other waves may have
+        // removed their tiles' head bits already, so the COUNT pass's per-tile heads answer: the nearest tile before / after
+        // with a head (64 tiles per look, issued with the tile's own loads).
+        constexpr bool may_peek = PASS == 0;
         const uint32_t pu = t1 + lane;
         const uint32_t peek = (may_peek && pu < n) ? a.post[pu].y >> 31 : 0u;
+        uint32_t hb = GT_NONE, ha = GT_NONE;
+        if constexpr (PASS == 1) {
+            hb = lane < tile ? a.th_last[tile - 1 - lane] : GT_NONE;
+            ha = tile + 1 + lane < tiles ? a.th_first[tile + 1 + lane] : GT_NONE;
+        }
         // (shard modes) "this gene gets ranges" for all sixteen records at once: behind the ballots below each lookup would
         // wait for the one before it
         uint32_t ins = 0xffffffffu;
         if constexpr (MODE == 0 || MODE == 2) {
-            uint8_t inb[GW_ROUNDS];
-#pragma unroll
-            for (int j = 0; j < GW_ROUNDS; j++) inb[j] = a.in_shard[po[j].x];
             ins = 0;
+            if (n_iv) {                                  // (uniform) sixteen independent binary searches over the interval starts, in LDS
+                uint32_t lo_i[GW_ROUNDS], hi_i[GW_ROUNDS];
 #pragma unroll
-            for (int j = 0; j < GW_ROUNDS; j++) ins |= (uint32_t) (inb[j] != 0) << j;
+                for (int j = 0; j < GW_ROUNDS; j++) { lo_i[j] = 0; hi_i[j] = n_iv; }          // last interval with start <= gene is lo_i - 1
+                for (uint32_t span = n_iv; span > 0; span >>= 1) {
+#pragma unroll
+                    for (int j = 0; j < GW_ROUNDS; j++) {
+                        const uint32_t mid = (lo_i[j] + hi_i[j]) >> 1;
+                        const bool go = lo_i[j] < hi_i[j] && s_iv[mid < n_iv ? mid : n_iv - 1].x <= po[j].x;
+                        if (lo_i[j] < hi_i[j]) { if (go) lo_i[j] = mid + 1; else hi_i[j] = mid; }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < GW_ROUNDS; j++) ins |= (uint32_t) (lo_i[j] > 0 && po[j].x < s_iv[lo_i[j] > 0 ? lo_i[j] - 1 : 0].y) << j;
+            } else {
+                uint8_t inb[GW_ROUNDS];
+#pragma unroll
+                for (int j = 0; j < GW_ROUNDS; j++) inb[j] = a.in_shard[po[j].x];
+#pragma unroll
+                for (int j = 0; j < GW_ROUNDS; j++) ins |= (uint32_t) (inb[j] != 0) << j;
+            }
         }
         unsigned long long m[GW_ROUNDS];
 #pragma unroll
         for (int j = 0; j < GW_ROUNDS; j++) m[j] = __ballot(t0 + j * PDL_WAVE + lane < n && (po[j].y >> 31));
         // head of the group that runs into the tile
-        uint32_t before = last_head;
-        if (before == GT_NONE && !(m[0] & 1ull)) {       // (uniform) first tile of the wave's run and it starts inside a group
-            if constexpr (PASS == 0) before = find_head_back(a.post, t0 - 1, lane);      // (t0 > 0: record 0 is a head)
+        uint32_t before = t0;
+        if (!(m[0] & 1ull)) {                            // (uniform) the tile starts inside a group (t0 > 0: record 0 is a head)
+            if constexpr (PASS == 0) before = find_head_back(a.post, t0 - 1, lane);
             else {
-                before = 0;
-                for (uint32_t hi = tile; hi > 0;) {      // last head of the tiles before, 64 tiles per step
-                    const uint32_t base = hi >= PDL_WAVE ? hi - PDL_WAVE : 0, idx = base + lane;
-                    const uint32_t v = idx < hi ? a.th_last[idx] : GT_NONE;
-                    const unsigned long long hm = __ballot(v != GT_NONE);
-                    if (hm) { before = (uint32_t) __shfl((int) v, 63 - __clzll((long long) hm), PDL_WAVE); break; }
-                    hi = base;
+                unsigned long long hm = __ballot(hb != GT_NONE);
+                if (hm) before = (uint32_t) __shfl((int) hb, __ffsll((long long) hm) - 1, PDL_WAVE);        // lane 0 = the tile just before
+                else {
+                    before = 0;
+                    for (uint32_t hi = tile >= PDL_WAVE ? tile - PDL_WAVE : 0; hi > 0;) {                    // further back, 64 tiles per step
+                        const uint32_t base = hi >= PDL_WAVE ? hi - PDL_WAVE : 0, idx = base + lane;
+                        const uint32_t v = idx < hi ? a.th_last[idx] : GT_NONE;
+                        hm = __ballot(v != GT_NONE);
+                        if (hm) { before = (uint32_t) __shfl((int) v, 63 - __clzll((long long) hm), PDL_WAVE); break; }
+                        hi = base;
+                    }
                 }
             }
         }
         // end of the group that runs out of the tile
         uint32_t after;
-        {
+        if constexpr (PASS == 0) {
             const unsigned long long pm = __ballot(peek != 0);
             if (pm) after = t1 + (uint32_t) __ffsll((long long) pm) - 1u;
-            else if (t1 + PDL_WAVE >= n && may_peek) after = n;
-            else if constexpr (PASS == 0) after = find_head_fwd(a.post, t1 + PDL_WAVE, n, lane);
+            else if (t1 + PDL_WAVE >= n) after = n;
+            else after = find_head_fwd(a.post, t1 + PDL_WAVE, n, lane);
+        } else {
+            unsigned long long hm = __ballot(ha != GT_NONE);
+            if (hm) after = (uint32_t) __shfl((int) ha, __ffsll((long long) hm) - 1, PDL_WAVE);
             else {
                 after = n;
-                for (uint32_t lo = tile + 1; lo < tiles; lo += PDL_WAVE) {
+                for (uint32_t lo = tile + 1 + PDL_WAVE; lo < tiles; lo += PDL_WAVE) {
                     const uint32_t idx = lo + lane;
                     const uint32_t v = idx < tiles ? a.th_first[idx] : GT_NONE;
-                    const unsigned long long hm = __ballot(v != GT_NONE);
+                    hm = __ballot(v != GT_NONE);
                     if (hm) { after = (uint32_t) __shfl((int) v, __ffsll((long long) hm) - 1, PDL_WAVE); break; }
                 }
             }
@@ -547,7 +580,7 @@ __global__ __launch_bounds__(GW_THREADS) void k_group_waves(GroupTileArgs a) {
             if (m[j]) { nx = t0 + j * PDL_WAVE + (uint32_t) __ffsll((long long) m[j]) - 1u; first_in_tile = nx; }
         }
         uint32_t pr = before, cnt_tile = 0;              // (uniform) last head before the current round; ranges so far in the tile
-        const uint32_t tile_prefix = PASS == 1 ? chunk_prefix + a.tile_sums[tile] : 0u;
+        const uint32_t tile_prefix = PASS == 1 ? a.chunk_sums[tile / PDL_WAVE] + a.tile_sums[tile] : 0u;
 #pragma unroll
         for (int j = 0; j < GW_ROUNDS; j++) {
             const uint32_t u = t0 + j * PDL_WAVE + lane;
@@ -589,13 +622,10 @@ __global__ __launch_bounds__(GW_THREADS) void k_group_waves(GroupTileArgs a) {
             if (m[j]) pr = t0 + j * PDL_WAVE + 63u - (uint32_t) __clzll((long long) m[j]);
         }
         if constexpr (PASS == 0) {
-            if (lane == 0) { a.tile_sums[tile] = running; a.th_first[tile] = first_in_tile; a.th_last[tile] = first_in_tile != GT_NONE ? pr : GT_NONE; }
-            running += cnt_tile;
+            if (lane == 0) { a.tile_sums[tile] = cnt_tile; a.th_first[tile] = first_in_tile; a.th_last[tile] = first_in_tile != GT_NONE ? pr : GT_NONE; }
         }
-        last_head = pr;
     }
     if constexpr (PASS == 0) {
-        if (lane == 0) a.chunk_sums[gw] = running;
 #pragma unroll
         for (int d = PDL_WAVE / 2; d > 0; d >>= 1) { n_rec += __shfl_xor(n_rec, d, PDL_WAVE); n_grp += __shfl_xor(n_grp, d, PDL_WAVE); }
         if (lane == 0) { atomicAdd(&s_red[0], n_rec); atomicAdd(&s_red[1], n_grp); }
@@ -608,6 +638,103 @@ __global__ __launch_bounds__(GW_THREADS) void k_group_waves(GroupTileArgs a) {
             }
         }
     }
+}
+
+// COUNT for the range modes, per-thread code (the mask arithmetic of k_group_waves keeps a wave's uniform values in
+// vector registers and ran at a quarter of the streaming rate): a record gets a range iff its successor does not open a
+// group [and its gene belongs to the shard]; MODE 0: iff it is not alone in its group.  One wave per 1024-record tile.
+// Also leaves the first / last head of every tile for the WRITE pass, and the counters U' / shared groups.
+template <int MODE>
+__global__ __launch_bounds__(GW_THREADS) void k_range_count(GroupTileArgs a) {
+    extern __shared__ unsigned long long s_dyn[];
+    __shared__ uint32_t s_red[2];
+    uint2 *s_iv = reinterpret_cast<uint2 *>(s_dyn);
+    const uint32_t n_iv = (MODE == 0 || MODE == 2) ? a.n_own_iv : 0u;
+    if constexpr (MODE == 0 || MODE == 2) { for (uint32_t i = threadIdx.x; i < n_iv; i += GW_THREADS) s_iv[i] = a.own_iv[i]; }
+    if (threadIdx.x < 2) s_red[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t tid = threadIdx.x, lane = tid & (PDL_WAVE - 1);
+    const uint32_t gw = blockIdx.x * GW_WAVES + tid / PDL_WAVE;
+    const uint32_t n = (uint32_t) scan_count(a.n_bound, a.d_n);
+    const uint32_t tiles = (n + GW_TILE - 1) / GW_TILE;
+    uint32_t n_rec = 0, n_grp = 0;
+    for (uint32_t tile = gw; tile < tiles; tile += gridDim.x * GW_WAVES) {
+        const uint32_t t0 = tile * GW_TILE;
+        uint2 po[GW_ROUNDS];
+        uint32_t ynext[GW_ROUNDS];
+#pragma unroll
+        for (int j = 0; j < GW_ROUNDS; j++) {            // all loads first, branch-free
+            const uint32_t u = t0 + j * PDL_WAVE + lane;
+            po[j] = a.post[u < n ? u : n - 1];
+            ynext[j] = a.post[u + 1 < n ? u + 1 : n - 1].y;
+        }
+        uint32_t ins = 0xffffffffu;
+        if constexpr (MODE == 0 || MODE == 2) {
+            ins = 0;
+            if (n_iv) {                                  // (uniform) sixteen independent binary searches over the interval starts, in LDS
+                uint32_t lo_i[GW_ROUNDS], hi_i[GW_ROUNDS];
+#pragma unroll
+                for (int j = 0; j < GW_ROUNDS; j++) { lo_i[j] = 0; hi_i[j] = n_iv; }
+                for (uint32_t span = n_iv; span > 0; span >>= 1) {
+#pragma unroll
+                    for (int j = 0; j < GW_ROUNDS; j++) {
+                        const uint32_t mid = (lo_i[j] + hi_i[j]) >> 1;
+                        const bool go = lo_i[j] < hi_i[j] && s_iv[mid < n_iv ? mid : n_iv - 1].x <= po[j].x;
+                        if (lo_i[j] < hi_i[j]) { if (go) lo_i[j] = mid + 1; else hi_i[j] = mid; }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < GW_ROUNDS; j++) ins |= (uint32_t) (lo_i[j] > 0 && po[j].x < s_iv[lo_i[j] > 0 ? lo_i[j] - 1 : 0].y) << j;
+            } else {
+                uint8_t inb[GW_ROUNDS];
+#pragma unroll
+                for (int j = 0; j < GW_ROUNDS; j++) inb[j] = a.in_shard[po[j].x];
+#pragma unroll
+                for (int j = 0; j < GW_ROUNDS; j++) ins |= (uint32_t) (inb[j] != 0) << j;
+            }
+        }
+        uint32_t cnt = 0, first_h = GT_NONE, last_h = 0, any_h = 0;
+#pragma unroll
+        for (int j = 0; j < GW_ROUNDS; j++) {
+            const uint32_t u = t0 + j * PDL_WAVE + lane;
+            const bool live = u < n;
+            const bool head = live && (po[j].y >> 31);
+            const bool next_head = u + 1 >= n || (ynext[j] >> 31);           // the successor opens a group, or is the end
+            const bool shared = live && !(head && next_head);
+            bool r = MODE == 0 ? shared : (live && !next_head);
+            if constexpr (MODE == 0 || MODE == 2) r = r && ((ins >> j) & 1u);
+            cnt += r;
+            n_rec += shared; n_grp += head && !next_head;
+            if (head) { first_h = min(first_h, u); last_h = max(last_h, u); any_h = 1; }
+        }
+#pragma unroll
+        for (int d = PDL_WAVE / 2; d > 0; d >>= 1) {
+            cnt += __shfl_xor(cnt, d, PDL_WAVE);
+            first_h = min(first_h, (uint32_t) __shfl_xor((int) first_h, d, PDL_WAVE));
+            last_h = max(last_h, (uint32_t) __shfl_xor((int) last_h, d, PDL_WAVE));
+            any_h |= (uint32_t) __shfl_xor((int) any_h, d, PDL_WAVE);
+        }
+        if (lane == 0) { a.tile_sums[tile] = cnt; a.th_first[tile] = first_h; a.th_last[tile] = any_h ? last_h : GT_NONE; }
+    }
+#pragma unroll
+    for (int d = PDL_WAVE / 2; d > 0; d >>= 1) { n_rec += __shfl_xor(n_rec, d, PDL_WAVE); n_grp += __shfl_xor(n_grp, d, PDL_WAVE); }
+    if (lane == 0) { atomicAdd(&s_red[0], n_rec); atomicAdd(&s_red[1], n_grp); }
+    __syncthreads();
+    if (tid < 2 && s_red[tid]) atomicAdd(&a.counters[tid], (unsigned long long) s_red[tid]);
+}
+
+// Between the passes: tile_sums[t] (ranges of tile t) becomes the count of the tiles before t inside its block of 64 tiles,
+// chunk_sums[b] the block's total (scanned next); one wave per block.
+__global__ __launch_bounds__(256) void k_tile_prefix(uint32_t *__restrict__ tile_sums, const uint64_t *d_n, uint64_t n_bound,
+                                                     uint32_t *__restrict__ chunk_sums, uint32_t n_blocks) {
+    const uint32_t b = blockIdx.x * 4 + threadIdx.x / PDL_WAVE, lane = threadIdx.x & (PDL_WAVE - 1);
+    if (b >= n_blocks) return;
+    const uint32_t tiles = (uint32_t) ((scan_count(n_bound, d_n) + GW_TILE - 1) / GW_TILE);
+    const uint32_t t = b * PDL_WAVE + lane;
+    const uint32_t v = t < tiles ? tile_sums[t] : 0u;
+    const uint32_t inc = wave_inclusive_scan_u32(v);
+    if (t < tiles) tile_sums[t] = inc - v;
+    if (lane == PDL_WAVE - 1) chunk_sums[b] = inc;
 }
 
 // in_shard[gene] = the gene's genome belongs to this rank (multi-GPU: from the genome deal, without a host round trip)
@@ -798,8 +925,8 @@ static void stage_sort_and_dedup(pdl_ctx *c, KeyT *keys_in, KeyT *keys_out, uint
                    RecScatter<KeyT>{skeys, svals, m, c->recpos.as<uint32_t>(), c->post.as<uint2>()}, d_scal + 0);
 }
 
-// Launch helpers of k_group_waves.  group_tiles_plan sizes the grid (every wave owns a run of consecutive tiles) and the
-// scratch: tile_sums[tiles] | th_first[tiles] | th_last[tiles] | chunk_sums[waves].  Returns the number of workgroups.
+// Launch helpers of k_group_waves.  group_tiles_plan sizes the grid and the scratch: tile_sums[tiles] | th_first[tiles] |
+// th_last[tiles] | chunk_sums[blocks of 64 tiles].  Returns the number of workgroups.
 static uint32_t group_tiles_plan(pdl_ctx *c, GroupTileArgs &a) {
     const uint64_t tiles = (a.n_bound + GW_TILE - 1) / GW_TILE;
     if (tiles > 0x7fffffffull) PDL_FAIL(PDL_ERR_UNSUPPORTED, "dictionary of %llu records exceeds the grid limit", (unsigned long long) a.n_bound);
@@ -810,17 +937,16 @@ static uint32_t group_tiles_plan(pdl_ctx *c, GroupTileArgs &a) {
         if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) cus = prop.multiProcessorCount;
         c->cus = cus;
     }
-    const uint64_t want_waves = std::max<uint64_t>(1, std::min<uint64_t>(tiles, (uint64_t) cus * 8 * GW_WAVES));
-    a.tiles_per_chunk = (uint32_t) std::max<uint64_t>(1, (tiles + want_waves - 1) / want_waves);
-    const uint64_t waves = std::max<uint64_t>(1, (tiles + a.tiles_per_chunk - 1) / a.tiles_per_chunk);
-    const uint32_t grid = (uint32_t) ((waves + GW_WAVES - 1) / GW_WAVES);
-    c->scan_tmp.alloc(((size_t) tiles * 3 + (size_t) grid * GW_WAVES + 1) * sizeof(uint32_t));
+    a.n_blocks = (uint32_t) ((tiles + PDL_WAVE - 1) / PDL_WAVE);
+    const uint32_t grid = (uint32_t) std::max<uint64_t>(1, std::min<uint64_t>((tiles + GW_WAVES - 1) / GW_WAVES, (uint64_t) cus * 8));
+    c->scan_tmp.alloc(((size_t) tiles * 3 + a.n_blocks + 1) * sizeof(uint32_t));
     a.tile_sums = c->scan_tmp.as<uint32_t>(); a.th_first = a.tile_sums + tiles; a.th_last = a.th_first + tiles; a.chunk_sums = a.th_last + tiles;
     return grid;
 }
 template <int PASS, int MODE, bool GENOMES, bool RECORD_COSTS>
 static void launch_group_tiles(pdl_ctx *c, const GroupTileArgs &a, uint32_t grid) {
-    const size_t dyn = GENOMES && a.n_genomes <= COST_LDS_GENOMES ? 2 * (size_t) a.n_genomes * sizeof(uint64_t) : 0;
+    size_t dyn = GENOMES && a.n_genomes <= COST_LDS_GENOMES ? 2 * (size_t) a.n_genomes * sizeof(uint64_t) : 0;
+    if (MODE == 0 || MODE == 2) dyn = (size_t) a.n_own_iv * sizeof(uint2);
     hipLaunchKernelGGL((k_group_waves<PASS, MODE, GENOMES, RECORD_COSTS>), dim3(grid), dim3(GW_THREADS), dyn, c->stream, a);
     PDL_HIP(hipGetLastError());
 }
@@ -851,6 +977,25 @@ static void stage_ranges_and_costs(pdl_ctx *c, uint64_t bound, int mode, bool on
         uint32_t *v2a = reinterpret_cast<uint32_t *>(tuples + bound);
         uint32_t *k2b = v2a + bound;
         uint32_t *v2b = k2b + bound;
+        if (mode != 1) {                    // the shard as gene-id intervals, when every genome's genes are consecutive ids (the usual .faa)
+            std::vector<uint2> &iv = c->h_own_iv;
+            iv.clear();
+            bool contiguous = true;
+            for (uint32_t g : c->dict_shard) {           // (ascending genome ids; genomes in first-seen order: ascending gene ids too)
+                const uint32_t b = c->h_genome_row_off[g], e = c->h_genome_row_off[g + 1];
+                if (b == e) continue;
+                const uint32_t first = c->h_genome_rows[b], last = c->h_genome_rows[e - 1];
+                if (last - first + 1 != e - b) { contiguous = false; break; }
+                if (!iv.empty() && iv.back().y == first) iv.back().y = last + 1; else iv.push_back(make_uint2(first, last + 1));
+            }
+            if (contiguous) std::sort(iv.begin(), iv.end(), [](const uint2 &p, const uint2 &q) { return p.x < q.x; });
+            for (size_t i = 1; contiguous && i < iv.size(); i++) if (iv[i].x < iv[i - 1].y) contiguous = false;      // (cannot happen: genes belong to one genome)
+            if (contiguous && !iv.empty() && iv.size() <= GW_MAX_IV) {
+                c->own_iv.alloc(iv.size() * sizeof(uint2));
+                PDL_HIP(hipMemcpyAsync(c->own_iv.p, iv.data(), iv.size() * sizeof(uint2), hipMemcpyHostToDevice, st));
+                ga.own_iv = c->own_iv.as<uint2>(); ga.n_own_iv = (uint32_t) iv.size();
+            }
+        }
         if (mode != 1 && c->dist) {         // multi-GPU: the deal is on the device already (pdl_run_dist_finish)
             ga.in_shard = c->seq_in_shard.as<uint8_t>();
         } else if (mode != 1) {             // only the genes this context scores need range lists
@@ -865,10 +1010,15 @@ static void stage_ranges_and_costs(pdl_ctx *c, uint64_t bound, int mode, bool on
         }
         ga.key2 = k2a; ga.tuples = tuples;
         const uint64_t *d_us = d_scal + 2;       // ranges built = the total of the tile counts
-        if (mode == 1) launch_group_tiles<0, 1, false, false>(c, ga, grid);
-        else if (mode == 2) launch_group_tiles<0, 2, false, false>(c, ga, grid);
-        else launch_group_tiles<0, 0, false, false>(c, ga, grid);
-        hipLaunchKernelGGL(k_scan_tile_scan, dim3(1), dim3(1024), 0, st, ga.chunk_sums, grid * GW_WAVES, d_scal + 2, (uint64_t *) nullptr);
+        {
+            const size_t dyn = (size_t) ga.n_own_iv * sizeof(uint2);
+            if (mode == 1) hipLaunchKernelGGL(k_range_count<1>, dim3(grid), dim3(GW_THREADS), 0, st, ga);
+            else if (mode == 2) hipLaunchKernelGGL(k_range_count<2>, dim3(grid), dim3(GW_THREADS), dyn, st, ga);
+            else hipLaunchKernelGGL(k_range_count<0>, dim3(grid), dim3(GW_THREADS), dyn, st, ga);
+            PDL_HIP(hipGetLastError());
+        }
+        hipLaunchKernelGGL(k_tile_prefix, dim3((ga.n_blocks + 3) / 4), dim3(256), 0, st, ga.tile_sums, ga.d_n, ga.n_bound, ga.chunk_sums, ga.n_blocks);
+        hipLaunchKernelGGL(k_scan_tile_scan, dim3(1), dim3(1024), 0, st, ga.chunk_sums, ga.n_blocks, d_scal + 2, (uint64_t *) nullptr);
         if (mode == 1) launch_group_tiles<1, 1, false, false>(c, ga, grid);
         else if (mode == 2) launch_group_tiles<1, 2, false, false>(c, ga, grid);
         else launch_group_tiles<1, 0, false, false>(c, ga, grid);

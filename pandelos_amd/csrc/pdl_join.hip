@@ -149,7 +149,7 @@ struct JoinCfg {
 };
 
 template <int HT_BITS_, int T_, bool FILTER>
-__global__ __launch_bounds__(T_, (FILTER && HT_BITS_ == 10) ? 5 : 1) void k_join_lds(JoinArgs a) {
+__global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join_lds(JoinArgs a) {
     using Cfg = JoinCfg<HT_BITS_, T_, FILTER>;
     constexpr uint32_t HT = Cfg::HT, LIMIT = Cfg::LIMIT, TOUCH_CAP = Cfg::TOUCH_CAP, RB = Cfg::RB, RPT = Cfg::RPT;
     constexpr int T = T_;

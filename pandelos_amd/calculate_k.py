@@ -38,3 +38,8 @@ def calculate_k_faa(path) -> int:
                 for s in line.strip():
                     alphabet[s] = alphabet.get(s, 0) + 1
     return _k_from_counts(alphabet.values())
+
+
+if __name__ == "__main__":      # the line pandelos.sh greps for (pandelos.sh:67-68)
+    import sys
+    print("k = ", calculate_k_faa(sys.argv[1]))

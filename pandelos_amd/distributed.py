@@ -118,13 +118,15 @@ class DistributedPangenes:
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
         self.exchange_s = {"dictionary": 0.0, "cells": 0.0}
+        import os
+        self.p2p_gather = os.environ.get("PDL_DIST_GATHER", "p2p") != "broadcast"     # how the runs are gathered on device tensors
 
     # exchange of the dictionary runs: full[offs[p] : offs[p+1]] <- rank p's run, for every p
     def _all_gather_runs(self, full, offs):
         import torch
         import torch.distributed as dist
         r, W = self.rank, self.world
-        if self.on_device:
+        if self.on_device and self.p2p_gather:
             ops = []
             mine = full[offs[r]:offs[r + 1]]
             for step in range(1, W):        # peer order staggered per rank: every link is busy from the start
@@ -136,6 +138,10 @@ class DistributedPangenes:
             if ops:
                 for req in dist.batch_isend_irecv(ops):
                     req.wait()
+        elif self.on_device:                # PDL_DIST_GATHER=broadcast: one broadcast per run, in place (no point-to-point calls)
+            for p in range(W):
+                if offs[p + 1] > offs[p]:
+                    dist.broadcast(full[offs[p]:offs[p + 1]], src=p)
         else:
             host = torch.empty(int(offs[-1]), dtype=torch.int64)
             host[offs[r]:offs[r + 1]] = full[offs[r]:offs[r + 1]].cpu()

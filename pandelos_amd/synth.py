@@ -42,7 +42,9 @@ class GeneSet:
 
 
 def make_gene_set(genomes: int, genes_per_genome: int, mean_len: int, sub_rate: float, seed: int,
-                  presence: float = 0.85) -> GeneSet:
+                  presence: float = 0.85, paralogs: float = 0.0) -> GeneSet:
+    """``paralogs``: fraction of a genome's families that get a second, independently mutated copy in that genome
+    (in-genome duplicates make the gene network hold same-genome genes in one component: the case netclu splits)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     fams = max(1, int(round(genes_per_genome / presence)))
     lens = np.clip(rng.normal(mean_len, mean_len / 4.0, fams).astype(np.int64), 20, None)
@@ -55,6 +57,8 @@ def make_gene_set(genomes: int, genes_per_genome: int, mean_len: int, sub_rate: 
         present = np.nonzero(rng.random(fams) < presence)[0]
         if len(present) == 0:
             present = np.array([g % fams])
+        if paralogs > 0.0:                      # (no random draw without paralogs: earlier (shape, seed) pairs keep their bytes)
+            present = np.concatenate([present, present[rng.random(len(present)) < paralogs]])
         ln = lens[present]
         total = int(ln.sum())
         excl = np.zeros(len(ln), np.int64)

@@ -1,22 +1,38 @@
 #!/bin/bash
 # pandelos_mi355x.sh — same plugin surface as the reference's pandelos.sh (pandelos.sh:44-81):
 #     bash pandelos_mi355x.sh <dataset.faa> <out_prefix>      ->   <out_prefix>.clus
-# The k selection and the de-clustering stay the reference's scripts (calculate_k.py, netclu_ng.py: set
-# PANDELOS_PATH to a PanDelos checkout); the Java stage in the middle (pandelos.sh:73) is replaced by the native
-# MI355X host built by `python __graft_entry__.py` (pandelos_amd/lib/pangenes; the JVM route is to point
-# -Djava.library.path at pandelos_amd/lib instead).
+# Three stages, as there: k selection, the gene network (.net), de-clustering into gene families (.clus).
+#   * The Java stage in the middle (pandelos.sh:73) is the native MI355X host built by `python __graft_entry__.py`
+#     (pandelos_amd/lib/pangenes; the JVM route is to point -Djava.library.path at pandelos_amd/lib instead, see
+#     INTEGRATION.md).
+#   * With PANDELOS_PATH set to a PanDelos checkout, k selection and de-clustering are the reference's own scripts
+#     (calculate_k.py, netclu_ng.py — needs networkx); without it, this repository's restatements of the two
+#     (pandelos_amd/calculate_k.py, pandelos_amd/netclu.py), which the tests pin to the reference's outputs.
 sdir="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
-ref="${PANDELOS_PATH:?set PANDELOS_PATH to the PanDelos checkout that holds calculate_k.py and netclu_ng.py}"
+ref="${PANDELOS_PATH:-}"
 idb="$1"; oprefix="$2"
 if [ ! -f "$idb" ]; then echo "ERROR: input dataset file not found: $idb !"; echo "usage is: pandelos_mi355x.sh dataset.faa out_prefix"; exit; fi
 if [ -z "$oprefix" ]; then echo "ERROR: output prefix not given !"; echo "usage is: pandelos_mi355x.sh dataset.faa out_prefix"; exit; fi
 tmp=$(mktemp -p ./ -t "$(basename "$idb" .faa).XXXXXX")
 dnet="${tmp}.net"; clus="${oprefix}.clus"
-python3 "$ref/calculate_k.py" "$idb" > "$tmp"
+echo "calculating k ..."
+if [ -n "$ref" ]; then
+    python3 "$ref/calculate_k.py" "$idb" > "$tmp"
+else
+    PYTHONPATH="$sdir" python3 -m pandelos_amd.calculate_k "$idb" > "$tmp"
+fi
 k=$(grep -E "^k =" "$tmp" | sed s/k\ =\ //g)
 echo "k = $k"
-"$sdir/pandelos_amd/lib/pangenes" -i "$idb" -k $k -o "$dnet" > "$tmp"
-python3 "$ref/netclu_ng.py" "$idb" "$dnet" >> "$tmp"
-grep "F{ " "$tmp" | sed s/F{\ //g | sed s/}//g | sed s/\ \;//g | sort | uniq > "$clus"
-rm "$tmp"
+echo "clustering ..."
+"$sdir/pandelos_amd/lib/pangenes" -i "$idb" -k $k -o "$dnet" > "$tmp" || { echo "ERROR: the native stage failed"; cat "$tmp"; rm -f "$tmp" "$dnet"; exit 1; }
+echo "de-clustering ..."
+if [ -n "$ref" ]; then
+    python3 "$ref/netclu_ng.py" "$idb" "$dnet" >> "$tmp"
+    echo "writing gene gene families in $clus ..."
+    grep "F{ " "$tmp" | sed s/F{\ //g | sed s/}//g | sed s/\ \;//g | LC_ALL=C sort | uniq > "$clus"
+else
+    echo "writing gene gene families in $clus ..."
+    PYTHONPATH="$sdir" python3 -m pandelos_amd.netclu "$idb" "$dnet" > "$clus"
+fi
+rm -f "$tmp" "$dnet"
 echo "Finish!"

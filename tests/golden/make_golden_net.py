@@ -25,6 +25,9 @@ CASES = {
     "synth_5x60x80_k3": (dict(genomes=5, genes_per_genome=60, mean_len=80, sub_rate=0.08, seed=1), 3),
     "synth_8x300x200_k4_div25": (dict(genomes=8, genes_per_genome=300, mean_len=200, sub_rate=0.25, seed=11), 4),
     "synth_12x100x100_k3_near_identical": (dict(genomes=12, genes_per_genome=100, mean_len=100, sub_rate=0.02, seed=5), 3),
+    # in-genome duplicates: components that hold two genes of one genome -> netclu_ng.py's Girvan-Newman splitting
+    "paralogs_6x80x120_k3": (dict(genomes=6, genes_per_genome=80, mean_len=120, sub_rate=0.12, seed=21, paralogs=0.35), 3),
+    "paralogs_10x60x90_k3_div20": (dict(genomes=10, genes_per_genome=60, mean_len=90, sub_rate=0.20, seed=22, paralogs=0.5), 3),
 }
 
 

@@ -22,6 +22,8 @@ CASES = {
     "synth_5x60x80_k3": (dict(genomes=5, genes_per_genome=60, mean_len=80, sub_rate=0.08, seed=1), 3),
     "synth_8x300x200_k4_div25": (dict(genomes=8, genes_per_genome=300, mean_len=200, sub_rate=0.25, seed=11), 4),
     "synth_12x100x100_k3_near_identical": (dict(genomes=12, genes_per_genome=100, mean_len=100, sub_rate=0.02, seed=5), 3),
+    "paralogs_6x80x120_k3": (dict(genomes=6, genes_per_genome=80, mean_len=120, sub_rate=0.12, seed=21, paralogs=0.35), 3),
+    "paralogs_10x60x90_k3_div20": (dict(genomes=10, genes_per_genome=60, mean_len=90, sub_rate=0.20, seed=22, paralogs=0.5), 3),
 }
 
 
@@ -107,3 +109,23 @@ def test_native_host_binary_writes_the_fixture_net(tmp_path):
     assert "Total cost:" in p.stdout
     bad = subprocess.run([str(_lib.LIB_DIR / "pangenes"), "-i", str(faa)], capture_output=True, text=True, timeout=60)
     assert bad.returncode == 1 and "Error while parsing cli arguments!" in bad.stdout      # Cli.java:83-87
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["synth_5x60x80_k3", "paralogs_6x80x120_k3"])
+def test_wrapper_script_goes_from_faa_to_the_fixture_clus(name, tmp_path):
+    """pandelos_mi355x.sh <in.faa> <prefix>: k selection, the native stage on the GPU, de-clustering — without a PanDelos
+    checkout (this repository's own calculate_k / netclu).  The .clus equals the one the reference's scripts made."""
+    import os
+    shape, k = CASES[name]
+    gs = make_gene_set(**shape)
+    faa = tmp_path / "in.faa"
+    gs.write_faa(faa)
+    env = {kk: v for kk, v in os.environ.items() if kk != "PANDELOS_PATH"}
+    p = subprocess.run(["bash", str(H.GOLDEN.parents[1] / "pandelos_mi355x.sh"), str(faa), str(tmp_path / "out")], capture_output=True, text=True,
+                       cwd=tmp_path, env=env, timeout=600)
+    assert p.returncode == 0 and "Finish!" in p.stdout, p.stdout + p.stderr
+    import re
+    assert re.search(rf"k =\s+{k}\b", p.stdout), p.stdout
+    assert (tmp_path / "out.clus").read_text() == (NET / f"{name}.clus").read_text()
+    assert sorted(x.name for x in tmp_path.iterdir()) == ["in.faa", "out.clus"]          # temporaries are gone

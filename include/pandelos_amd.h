@@ -147,6 +147,19 @@ PDL_API int pdl_score_all(pdl_ctx *);
 PDL_API int pdl_compute_scores(pdl_ctx *, uint32_t genome, pdl_scores *out);
 PDL_API void pdl_free_scores(pdl_scores *);
 
+/* The host stage behind computeScores, on the device: the bidirectional-best-hit filter of Pangenes.java:98-176 over one
+ * genome task's cells.  Returns the edges that task adds to the network in the host's insertion order — phase 1 (inter-genome
+ * best hits, (row, column) then (column, row) per cell), then phase 2 (kept intra-genome cells) — i.e. exactly the
+ * addConnection calls of Pangenes.java:103-104,171-175; what is left to the host is the network container and its
+ * text form (PangeneNet.java).  The first call filters every genome of the context and brings all edges to the host once. */
+typedef struct {
+    uint32_t count;
+    int32_t *src, *dst;            /* [count] gene ids */
+    float *score;                  /* [count] */
+} pdl_edges;
+PDL_API int pdl_compute_edges(pdl_ctx *, uint32_t genome, pdl_edges *out);
+PDL_API void pdl_free_edges(pdl_edges *);
+
 /* Number of emitted cells per genome after pdl_score_all ([G], 0 for genomes outside the shard) */
 PDL_API int pdl_scores_counts(pdl_ctx *, uint32_t *out_counts);
 

@@ -61,6 +61,10 @@ class PdlTimings(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
 
 
+class PdlEdges(C.Structure):
+    _fields_ = [("count", C.c_uint32), ("src", C.POINTER(C.c_int32)), ("dst", C.POINTER(C.c_int32)), ("score", C.POINTER(C.c_float))]
+
+
 class PdlDistSlice(C.Structure):
     _fields_ = [("d_postings", C.c_void_p), ("records", C.c_uint64), ("kmers", C.c_uint64),
                 ("genome_weights", C.POINTER(C.c_uint64)), ("genomes", C.c_uint32)]
@@ -78,7 +82,8 @@ EXPORTS = ("pdl_create", "pdl_destroy", "pdl_last_error", "pdl_preprocess", "pdl
            "pdl_genome_cost", "pdl_sequence_costs", "pdl_set_genome_shard", "pdl_score_all", "pdl_compute_scores",
            "pdl_free_scores", "pdl_scores_counts", "pdl_get_dictionary", "pdl_get_rank_table", "pdl_get_timings",
            "pdl_version", "pdl_set_option", "pdl_dist_preprocess_begin", "pdl_dist_preprocess_finish",
-           "pdl_dist_genome_owner", "pdl_dist_score_begin", "pdl_dist_score_finish", "pdl_copy_device")
+           "pdl_dist_genome_owner", "pdl_dist_score_begin", "pdl_dist_score_finish", "pdl_copy_device",
+           "pdl_compute_edges", "pdl_free_edges")
 
 _lib = None
 
@@ -125,5 +130,7 @@ def load():
     lib.pdl_dist_score_begin.argtypes = [vp, C.POINTER(PdlDistOutbox)]; lib.pdl_dist_score_begin.restype = i32
     lib.pdl_dist_score_finish.argtypes = [vp, vp, u64]; lib.pdl_dist_score_finish.restype = i32
     lib.pdl_copy_device.argtypes = [vp, vp, vp, u64]; lib.pdl_copy_device.restype = i32
+    lib.pdl_compute_edges.argtypes = [vp, u32, C.POINTER(PdlEdges)]; lib.pdl_compute_edges.restype = i32
+    lib.pdl_free_edges.argtypes = [C.POINTER(PdlEdges)]; lib.pdl_free_edges.restype = None
     _lib = lib
     return lib

@@ -150,41 +150,19 @@ int main(int argc, char **argv) {
     if (complexity) { pdl_destroy(ctx); return 0; }                           // Pangenes.java:33-36
 
     // ---- per-genome tasks, Pangenes.java:60-183 ------------------------------------------------------------
+    // The best-hit filter of the task (:98-176) runs on the device, over the cells where they are (pdl_compute_edges,
+    // pdl_bbh.hip); what arrives here are the task's addConnection calls in order.
     Net net;
+    std::vector<uint32_t> counts(G, 0);
+    if (pdl_scores_counts(ctx, counts.data()) != PDL_OK) { fprintf(stderr, "pandelos_amd: %s\n", pdl_last_error(ctx)); return 1; }
     for (uint32_t g = 0; g < G; g++) {
-        pdl_scores s;
-        if (pdl_compute_scores(ctx, g, &s) != PDL_OK) { fprintf(stderr, "pandelos_amd: %s\n", pdl_last_error(ctx)); return 1; }
+        pdl_edges e;
+        if (pdl_compute_edges(ctx, g, &e) != PDL_OK) { fprintf(stderr, "pandelos_amd: %s\n", pdl_last_error(ctx)); return 1; }
         uint64_t gcost = 0;
         (void) pdl_genome_cost(ctx, g, &gcost);
-        printf("Genome %u cost = %llu\nFiltered count: %u\n", g, (unsigned long long) gcost, s.scoresCount);   // library.cpp:535-538, Pangenes.java:68
-        const uint32_t z = s.scoresCount;
-        std::vector<float> inter_max(G, 0.0f);
-        std::vector<uint8_t> should_add(z, 0);
-        for (uint32_t i = 0; i < z; i++) {                                    // :98-128
-            if (s.first_seq_genome[i] == s.second_seq_genome[i]) continue;
-            const float sc = s.scores[i];
-            if (sc == s.max_genome_score[(size_t) s.scoresMaxMappings[s.row[i]] * G + s.second_seq_genome[i]] &&
-                sc == s.max_genome_score_col[s.column[i]]) {
-                net.add(s.row[i], s.column[i], sc);
-                net.add(s.column[i], s.row[i], sc);
-                should_add[i] = 1;
-                const int sg = s.second_seq_genome[i];
-                if ((double) sc < 1.0 && sc > inter_max[sg]) inter_max[sg] = sc;
-            }
-        }
-        std::vector<float> thr(n, std::numeric_limits<float>::infinity());   // :146-155
-        for (uint32_t i = 0; i < z; i++)
-            if (should_add[i]) thr[s.row[i]] = std::min(thr[s.row[i]], inter_max[s.second_seq_genome[i]]);
-        for (uint32_t i = 0; i < z; i++) {                                    // :164-176
-            if (s.row[i] < s.column[i] && s.first_seq_genome[i] == s.second_seq_genome[i]) {
-                const float sc = s.scores[i];
-                const int sg = s.second_seq_genome[i];
-                if (sc == s.max_genome_score[(size_t) s.scoresMaxMappings[s.row[i]] * G + sg] &&
-                    sc == s.max_genome_score[(size_t) s.scoresMaxMappings[s.column[i]] * G + sg] && sc >= thr[s.row[i]])
-                    net.add(s.row[i], s.column[i], sc);
-            }
-        }
-        pdl_free_scores(&s);
+        printf("Genome %u cost = %llu\nFiltered count: %u\n", g, (unsigned long long) gcost, counts[g]);   // library.cpp:535-538, Pangenes.java:68
+        for (uint32_t i = 0; i < e.count; i++) net.add(e.src[i], e.dst[i], e.score[i]);
+        pdl_free_edges(&e);
     }
     pdl_destroy(ctx);
 

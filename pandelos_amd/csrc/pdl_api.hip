@@ -63,6 +63,7 @@ void pdl_destroy(pdl_ctx *c) {
     if (c->own_stream && c->stream) (void) hipStreamDestroy(c->stream);
     if (c->pin) (void) hipHostFree(c->pin);
     if (c->mirror) (void) hipHostFree(c->mirror);
+    if (c->edge_mirror) (void) hipHostFree(c->edge_mirror);
     delete c;
 }
 
@@ -227,7 +228,7 @@ static int score_all_locked(pdl_ctx *c) {
     if (c->scored) return PDL_OK;
     if (c->dist) PDL_FAIL(PDL_ERR_STATE, "multi-GPU context: score with pdl_dist_score_begin / pdl_dist_score_finish");
     PDL_HIP(hipSetDevice(c->device));
-    c->mirror_valid = false;
+    c->mirror_valid = false; c->edges_valid = false;
     pdl_run_score_all(c);
     return PDL_OK;
     PDL_GUARD_END(c)
@@ -395,6 +396,47 @@ int pdl_compute_scores(pdl_ctx *c, uint32_t genome, pdl_scores *out) {
     } catch (const std::bad_alloc &) { { std::lock_guard<std::mutex> lk(c->mu); c->err = "host allocation failed"; } pdl_free_scores(out); return PDL_ERR_DEVICE; }
 }
 
+void pdl_free_edges(pdl_edges *e) {
+    if (!e) return;
+    free(e->src); free(e->dst); free(e->score);
+    memset(e, 0, sizeof(*e));
+}
+
+int pdl_compute_edges(pdl_ctx *c, uint32_t genome, pdl_edges *out) {
+    if (!c || !out) return PDL_ERR_ARGUMENT;
+    memset(out, 0, sizeof(*out));
+    try {
+    {
+        std::lock_guard<std::mutex> lk(c->mu);      // the scoring pass / the filter run once; slicing needs no lock
+        int rc = c->scored ? PDL_OK : score_all_locked(c);
+        if (rc != PDL_OK) return rc;
+        if (genome >= c->G) PDL_FAIL(PDL_ERR_ARGUMENT, "genome %u out of range (%u genomes)", genome, c->G);
+        if (c->h_local_genome[genome] < 0) PDL_FAIL(PDL_ERR_ARGUMENT, "genome %u is not in this context's shard", genome);
+        if (!c->edges_valid) {
+            PDL_HIP(hipSetDevice(c->device));
+            pdl_run_bbh_all(c);
+        }
+    }
+    const int32_t lg = c->h_local_genome[genome];
+    const uint64_t a1 = c->h_edge1[lg], b1 = c->h_edge1[lg + 1], a2 = c->h_edge_off[lg], b2 = c->h_edge_off[lg + 1];
+    const uint64_t n1 = c->n_edges1, n2 = c->n_edges - c->n_edges1;
+    const uint32_t cnt = (uint32_t) ((b1 - a1) + (b2 - a2));
+    out->count = cnt;
+    out->src = xalloc<int32_t>(cnt); out->dst = xalloc<int32_t>(cnt); out->score = xalloc<float>(cnt);
+    const uint8_t *m = c->edge_mirror;
+    const size_t k1 = (size_t) (b1 - a1), k2 = (size_t) (b2 - a2);
+    if (k1) {
+        memcpy(out->src, m + a1 * 4, k1 * 4); memcpy(out->dst, m + n1 * 4 + a1 * 4, k1 * 4); memcpy(out->score, m + n1 * 8 + a1 * 4, k1 * 4);
+    }
+    if (k2) {
+        const uint8_t *m2 = m + n1 * 12;
+        memcpy(out->src + k1, m2 + a2 * 4, k2 * 4); memcpy(out->dst + k1, m2 + n2 * 4 + a2 * 4, k2 * 4); memcpy(out->score + k1, m2 + n2 * 8 + a2 * 4, k2 * 4);
+    }
+    return PDL_OK;
+    } catch (const pdl_error &e) { { std::lock_guard<std::mutex> lk(c->mu); c->err = e.msg; } pdl_free_edges(out); return e.code;
+    } catch (const std::bad_alloc &) { { std::lock_guard<std::mutex> lk(c->mu); c->err = "host allocation failed"; } pdl_free_edges(out); return PDL_ERR_DEVICE; }
+}
+
 int pdl_set_option(pdl_ctx *c, const char *name, int64_t value) {
     if (!c || !name) return PDL_ERR_ARGUMENT;
     std::lock_guard<std::mutex> lk(c->mu);
@@ -467,7 +509,7 @@ int pdl_dist_score_begin(pdl_ctx *c, pdl_dist_outbox *out) {
     PDL_GUARD_BEGIN
     if (!c->dist || c->dist_stage < 2) PDL_FAIL(PDL_ERR_STATE, "pdl_dist_score_begin before pdl_dist_preprocess_finish");
     PDL_HIP(hipSetDevice(c->device));
-    c->scored = false; c->mirror_valid = false; c->dist_stage = 2;
+    c->scored = false; c->mirror_valid = false; c->edges_valid = false; c->dist_stage = 2;
     pdl_run_dist_score_begin(c);
     out->d_cells = c->outbox.as<pdl_dist_cell>();
     out->counts = c->h_outbox_counts.data();

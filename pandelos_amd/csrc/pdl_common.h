@@ -170,6 +170,15 @@ struct pdl_ctx {
     int cus = 0;
     uint32_t occ_tier1[5] = {0, 0, 0, 0, 0};
 
+    // K-bbh (pdl_bbh.hip): network edges of every genome task, on the host after the first pdl_compute_edges
+    bool edges_valid = false;
+    DevBuf bbh_kind, bbh_tab, e_src, e_dst, e_score;
+    uint8_t *edge_mirror = nullptr;           // pinned: src1 | dst1 | score1 (phase 1) | src2 | dst2 | score2 (phase 2)
+    size_t edge_mirror_bytes = 0;
+    uint64_t n_edges = 0, n_edges1 = 0;
+    std::vector<uint32_t> h_bbh_at;
+    std::vector<uint64_t> h_edge1, h_edge_off;   // [shard+1] first phase-1 / phase-2 edge of every genome task
+
     // tuning / test switches (pdl_set_option)
     int opt_tier1 = -1;           // -1: by genome count
     bool opt_tiny_tier2 = false;
@@ -236,6 +245,7 @@ void pdl_run_score_all(pdl_ctx *c);
 void pdl_run_dist_score_begin(pdl_ctx *c);
 void pdl_run_dist_score_finish(pdl_ctx *c, const pdl_dist_cell *d_inbox, uint64_t n_inbox);
 void pdl_prepare_tasks(pdl_ctx *c);
+void pdl_run_bbh_all(pdl_ctx *c);
 inline uint2 *pdl_postings(const pdl_ctx *c) { return c->post_ext ? c->post_ext : c->post.as<uint2>(); }
 
 // event helpers

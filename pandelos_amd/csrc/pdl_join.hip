@@ -1012,7 +1012,7 @@ void pdl_prepare_tasks(pdl_ctx *c) {
         c->owner_of_genome.alloc((size_t) G * 4);
         PDL_HIP(hipMemcpyAsync(c->owner_of_genome.p, c->h_owner.data(), (size_t) G * 4, hipMemcpyHostToDevice, st));
     }
-    if (!c->shard_set || S == G || c->dist) {   // mirror mode: every gene's task position (0xffffffff: another GPU's row) and every genome's CM row
+    {   // every gene's task position (0xffffffff: not a row of this context) and every genome's CM row: mirror mode, K-bbh
         c->h_taskpos_host.assign((size_t) N, 0xffffffffu);
         for (uint32_t q = 0; q < n_rows; q++) c->h_taskpos_host[c->h_task_rows_host[q]] = q;
         c->taskpos_of.alloc((size_t) N * 4);

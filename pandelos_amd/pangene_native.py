@@ -134,6 +134,17 @@ class PangeneNative:
             self._lib.pdl_free_scores(C.byref(s))
         return out
 
+    def generate_edges_part(self, genome: int):
+        """The best-hit filter of the Java host (Pangenes.java:98-176) for one genome task, run on the device: -> (src, dst,
+        score) of the edges the task adds to the network, in the host's insertion order."""
+        e = _lib.PdlEdges()
+        self._check(self._lib.pdl_compute_edges(self._ctx, int(genome), C.byref(e)))
+        try:
+            n = e.count
+            return (_np_copy(e.src, np.int32, n).astype(np.int64), _np_copy(e.dst, np.int32, n).astype(np.int64), _np_copy(e.score, np.float32, n))
+        finally:
+            self._lib.pdl_free_edges(C.byref(e))
+
     # -- beyond the reference surface (device-resident batch, sharding, introspection) ------------------
     def score_all(self) -> None:
         self._check(self._lib.pdl_score_all(self._ctx))

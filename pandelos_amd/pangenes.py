@@ -110,7 +110,12 @@ def net_lines(src: np.ndarray, dst: np.ndarray, score: np.ndarray) -> List[str]:
 
 def run(native, nof_genomes: int) -> List[str]:
     """Pangenes.main after the dictionary exists (:54-66,185-194,222-227), one worker."""
-    parts = [bbh_edges(native.generate_scores_part(g, False)) for g in range(nof_genomes)]
+    # the filter runs where the cells are: on the device (pdl_compute_edges); a `native` without that entry point (the
+    # tests' stand-in around the CPU oracle) gets the array form above applied to its Scores blocks
+    if hasattr(native, "generate_edges_part"):
+        parts = [native.generate_edges_part(g) for g in range(nof_genomes)]
+    else:
+        parts = [bbh_edges(native.generate_scores_part(g, False)) for g in range(nof_genomes)]
     if not parts:
         return []
     return net_lines(np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]),

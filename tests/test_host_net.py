@@ -129,3 +129,18 @@ def test_wrapper_script_goes_from_faa_to_the_fixture_clus(name, tmp_path):
     assert re.search(rf"k =\s+{k}\b", p.stdout), p.stdout
     assert (tmp_path / "out.clus").read_text() == (NET / f"{name}.clus").read_text()
     assert sorted(x.name for x in tmp_path.iterdir()) == ["in.faa", "out.clus"]          # temporaries are gone
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_device_filter_emits_the_hosts_edges_in_insertion_order(name):
+    """pdl_compute_edges (K-bbh on the device) against the array form of the filter applied to the same Scores blocks, edge
+    for edge and in order — and both against the loop-by-loop restatement of the Java through the .net fixture above."""
+    from pandelos_amd.pangene_native import PangeneNative
+    shape, k = CASES[name]
+    gs = make_gene_set(**shape)
+    nat = PangeneNative.from_arrays(k, gs.residues, gs.offsets, gs.genome_of)
+    for g in range(gs.genomes):
+        src, dst, sc = nat.generate_edges_part(g)
+        want = PH.bbh_edges(nat.generate_scores_part(g))
+        assert np.array_equal(src, want[0]) and np.array_equal(dst, want[1]) and np.array_equal(H.raw(sc), H.raw(want[2])), f"genome {g}"

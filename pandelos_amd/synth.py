@@ -41,20 +41,42 @@ class GeneSet:
                 f.write(b"\n")
 
 
+# Average amino-acid composition of proteins (per cent, UniProtKB/Swiss-Prot statistics, letters of ALPHABET order
+# A C D E F G H I K L M N P Q R S T V W Y) — for the "protein-like" stand-ins
+PROTEIN_COMPOSITION = np.array([8.25, 1.38, 5.46, 6.72, 3.86, 7.07, 2.27, 5.91, 5.80, 9.65,
+                                2.41, 4.06, 4.74, 3.93, 5.53, 6.64, 5.36, 6.86, 1.10, 2.92])
+LOW_COMPLEXITY_MOTIFS = (b"Q", b"GS", b"A", b"PE", b"KE", b"SR", b"N")
+
+
 def make_gene_set(genomes: int, genes_per_genome: int, mean_len: int, sub_rate: float, seed: int,
-                  presence: float = 0.85, paralogs: float = 0.0) -> GeneSet:
+                  presence: float = 0.85, paralogs: float = 0.0, protein_like: bool = False) -> GeneSet:
     """``paralogs``: fraction of a genome's families that get a second, independently mutated copy in that genome
-    (in-genome duplicates make the gene network hold same-genome genes in one component: the case netclu splits)."""
+    (in-genome duplicates make the gene network hold same-genome genes in one component: the case netclu splits).
+    ``protein_like``: residues drawn with the average composition of real proteins instead of uniformly (substitutions
+    too), a fifth of the families carry a low-complexity stretch (poly-Q, GS-linkers, ...: k-mers shared by unrelated
+    genes, many times over) and genomes differ in size — the cases uniform random text is kindest to."""
     rng = np.random.Generator(np.random.PCG64(seed))
     fams = max(1, int(round(genes_per_genome / presence)))
     lens = np.clip(rng.normal(mean_len, mean_len / 4.0, fams).astype(np.int64), 20, None)
     anc_off = np.zeros(fams + 1, np.int64)
     np.cumsum(lens, out=anc_off[1:])
     ancestors = rng.integers(0, 20, int(anc_off[-1]), dtype=np.uint8)
+    comp = None
+    genome_presence = np.full(genomes, presence)
+    if protein_like:
+        comp = PROTEIN_COMPOSITION / PROTEIN_COMPOSITION.sum()
+        ancestors = rng.choice(20, int(anc_off[-1]), p=comp).astype(np.uint8)
+        letter = {int(c): i for i, c in enumerate(ALPHABET)}
+        for f in np.nonzero(rng.random(fams) < 0.2)[0]:                    # low-complexity stretches
+            motif = LOW_COMPLEXITY_MOTIFS[int(rng.integers(0, len(LOW_COMPLEXITY_MOTIFS)))]
+            n = int(min(lens[f] - 2, rng.integers(8, 40)))
+            at = int(anc_off[f] + rng.integers(1, lens[f] - n))
+            ancestors[at:at + n] = np.array([letter[motif[i % len(motif)]] for i in range(n)], np.uint8)
+        genome_presence = np.clip(presence * rng.uniform(0.55, 1.1, genomes), 0.05, 1.0)   # genomes of different sizes
 
     chunks, gene_lens, genome_ids, fam_ids = [], [], [], []
     for g in range(genomes):
-        present = np.nonzero(rng.random(fams) < presence)[0]
+        present = np.nonzero(rng.random(fams) < genome_presence[g])[0]
         if len(present) == 0:
             present = np.array([g % fams])
         if paralogs > 0.0:                      # (no random draw without paralogs: earlier (shape, seed) pairs keep their bytes)
@@ -66,7 +88,10 @@ def make_gene_set(genomes: int, genes_per_genome: int, mean_len: int, sub_rate: 
         src = np.arange(total, dtype=np.int64) - np.repeat(excl, ln) + np.repeat(anc_off[present], ln)
         seq = ancestors[src]
         mut = rng.random(total) < sub_rate
-        seq = np.where(mut, rng.integers(0, 20, total, dtype=np.uint8), seq)
+        if comp is None:
+            seq = np.where(mut, rng.integers(0, 20, total, dtype=np.uint8), seq)
+        else:
+            seq = np.where(mut, rng.choice(20, total, p=comp).astype(np.uint8), seq)
         chunks.append(ALPHABET[seq])
         gene_lens.append(ln)
         genome_ids.append(np.full(len(ln), g, np.uint32))

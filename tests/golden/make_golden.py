@@ -77,6 +77,9 @@ LARGE = {
     "synth_40x60x40_k3": (dict(genomes=40, genes_per_genome=60, mean_len=40, sub_rate=0.08, seed=3), 3),
     "synth_16x1000x300_k5": (dict(genomes=16, genes_per_genome=1000, mean_len=300, sub_rate=0.08, seed=7), 5),
     "synth_8x300x200_k4_div25": (dict(genomes=8, genes_per_genome=300, mean_len=200, sub_rate=0.25, seed=11), 4),
+    # protein-like composition, low-complexity stretches shared by unrelated genes, genomes of different sizes
+    "protein_like_24x1500x300_k5": (dict(genomes=24, genes_per_genome=1500, mean_len=300, sub_rate=0.10, seed=2401, protein_like=True), 5),
+    "protein_like_12x400x150_k4_div30": (dict(genomes=12, genes_per_genome=400, mean_len=150, sub_rate=0.30, seed=2402, protein_like=True), 4),
 }
 
 
@@ -95,6 +98,23 @@ def raw(a):
 
 def main():
     assert ob.have_reference(), "run `make -C oracle` in the build container first"
+    only = set(sys.argv[1:])                      # names of LARGE cases: add / refresh just those digests
+    if only:
+        digests = json.loads((HERE / "digests.json").read_text())
+        for name in only:
+            shape, k = LARGE[name]
+            info, ref = run_ref(synth_faa(**shape), k)
+            digests[name] = {
+                "shape": shape, "k": k, "sequences": ref["sequences"], "genomes": ref["genomes"],
+                "total_cost": info["total_cost"],
+                "genome_cost": [info["genome_cost"][g] for g in range(ref["genomes"])],
+                "scoresCount": [int(d["scoresCount"]) for d in ref["per_genome"]],
+                "sha256": [{f: hashlib.sha256(raw(d[f]).tobytes()).hexdigest() for f in FIELDS}
+                           for d in ref["per_genome"]],
+            }
+            print(name, "genes", ref["sequences"], "cost", info["total_cost"], "cells", sum(digests[name]["scoresCount"]))
+        (HERE / "digests.json").write_text(json.dumps(digests, indent=1))
+        return
     for name, (faa, k) in SMALL.items():
         info, ref = run_ref(faa, k)
         out = {"faa": np.frombuffer(faa, np.uint8), "k": np.int64(k),

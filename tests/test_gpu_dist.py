@@ -59,10 +59,11 @@ def test_ranks_together_reproduce_the_fixture(name, world):
     lr.close()
 
 
-@pytest.mark.parametrize("weights", [True, False])      # the deal's weights: summed from the runs by the caller / computed by every rank
+@pytest.mark.parametrize("name", ["synth_16x1000x300_k5", "protein_like_24x1500x300_k5"])      # uniform text / protein-like composition with
+@pytest.mark.parametrize("weights", [True, False])      # low-complexity stretches; the deal's weights: from the runs / computed by every rank
 @pytest.mark.parametrize("world", [2, 4])
-def test_ranks_together_reproduce_the_reference_digest(world, weights):
-    res, off, gen, k, d = H.load_large("synth_16x1000x300_k5")
+def test_ranks_together_reproduce_the_reference_digest(world, weights, name):
+    res, off, gen, k, d = H.load_large(name)
     lr, cost = _local(world, res, off, gen, k, exchange_weights=weights)
     assert lr.total_cost == d["total_cost"]
     lr.score_all()

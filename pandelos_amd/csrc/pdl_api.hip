@@ -168,12 +168,20 @@ int pdl_preprocess_device(pdl_ctx *c, const uint8_t *d_residues, const uint64_t 
     return preprocess_common(c, n, n_res, k, only_complexity, out_cost);
 }
 
-int pdl_genome_cost(const pdl_ctx *c, uint32_t genome, uint64_t *out) {
+int pdl_genome_cost(const pdl_ctx *cc, uint32_t genome, uint64_t *out) {
+    pdl_ctx *c = const_cast<pdl_ctx *>(cc);
     if (!c || !out) return PDL_ERR_ARGUMENT;
+    std::lock_guard<std::mutex> lk(c->mu);
     if (!c->preprocessed) return PDL_ERR_STATE;
     if (genome >= c->G) return PDL_ERR_ARGUMENT;
+    PDL_GUARD_BEGIN
+    if (!c->costs_ready) {                       // (packed ranges: the per-gene / per-genome lookups are made on first request)
+        PDL_HIP(hipSetDevice(c->device));
+        pdl_ensure_costs(c);
+    }
     *out = c->h_genome_cost[genome];
     return PDL_OK;
+    PDL_GUARD_END(c)
 }
 
 int pdl_sequence_costs(const pdl_ctx *cc, uint64_t *out_cost, uint32_t *out_kseq) {
@@ -183,6 +191,7 @@ int pdl_sequence_costs(const pdl_ctx *cc, uint64_t *out_cost, uint32_t *out_kseq
     if (!c->preprocessed) return PDL_ERR_STATE;
     PDL_GUARD_BEGIN
     PDL_HIP(hipSetDevice(c->device));
+    pdl_ensure_costs(c);
     PDL_HIP(hipMemcpyAsync(out_cost, c->cost.p, (size_t) c->N * 8, hipMemcpyDeviceToHost, c->stream));
     if (out_kseq) PDL_HIP(hipMemcpyAsync(out_kseq, c->kseq_len.p, (size_t) c->N * 4, hipMemcpyDeviceToHost, c->stream));
     PDL_HIP(hipStreamSynchronize(c->stream));

@@ -123,6 +123,9 @@ struct pdl_ctx {
     DevBuf recpos;        // u32 [U+1] position of each record's first occurrence in the sorted stream
     DevBuf post;          // uint2 [U] {seq, count}  — the dictionary postings, rank-group major (bit 31 of count: opens a rank-group, until K-ranges removes it)
     DevBuf ranges;        // uint4 [U'] {group start, group length, own count, 0}, gene major
+    const uint2 *ranges8 = nullptr;   // packed 8-byte ranges (inside `scratch`, the gene sort's output) when the dataset allows: see GroupTileArgs::pay8
+    DevBuf head_bits;     // u64 [U / 64] "opens a rank-group" per record, kept by K-ranges for the per-gene costs made on demand
+    bool costs_ready = true;          // cost[] / h_genome_cost hold the per-gene / per-genome lookups (packed ranges: made on first request)
     DevBuf seq_off;       // u32 [N+1] range list of each gene
     bool upper_only = false;  // ranges hold only the columns above the row: the join mirrors every cell
     DevBuf scan_tmp;      // block sums of the scans
@@ -246,6 +249,7 @@ void pdl_run_dist_score_begin(pdl_ctx *c);
 void pdl_run_dist_score_finish(pdl_ctx *c, const pdl_dist_cell *d_inbox, uint64_t n_inbox);
 void pdl_prepare_tasks(pdl_ctx *c);
 void pdl_run_bbh_all(pdl_ctx *c);
+void pdl_ensure_costs(pdl_ctx *c);
 inline uint2 *pdl_postings(const pdl_ctx *c) { return c->post_ext ? c->post_ext : c->post.as<uint2>(); }
 
 // event helpers

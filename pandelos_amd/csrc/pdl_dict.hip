@@ -444,9 +444,13 @@ struct GroupTileArgs {
     uint32_t *chunk_sums;                       // [blocks of 64 tiles] ranges of a block; exclusive-scanned between the passes
     uint32_t n_blocks;
     uint32_t *th_first, *th_last;               // [tiles] first / last head of a tile (GT_NONE: none), COUNT -> WRITE
-    uint32_t *key2; uint4 *tuples;              // WRITE
+    uint32_t *key2; uint4 *tuples;              // WRITE: sort key (gene) and the 16-byte range tuple, or ...
+    unsigned long long *pay8;                   // ... (non-null) the packed 8-byte range {first posting | (postings + (min(own count, 1023) << 22)) << 32},
+                                                //     carried through the gene sort as its payload: no gather afterwards
+    unsigned long long *head_bits;              // WRITE: [tiles * 16] the head bits it removes from the postings, kept for the lazy cost pass
     unsigned long long *cost;                   // per-gene total_visited (library.cpp:327): last members (WRITE), all shared records (COUNT, RECORD_COSTS)
-    unsigned long long *counters;               // COUNT: [0] += records in groups >= 2, [1] += such groups
+    unsigned long long *counters;               // COUNT: [0] += records in groups >= 2, [1] += such groups;  WRITE: [2] += lookups of the
+                                                //        records that belong to this context (library.cpp:327 summed: "Total cost")
     const uint32_t *genome_of; uint32_t n_genomes;
     unsigned long long *g_full, *g_upper;       // COUNT, GENOMES: per genome, lookups as the reference counts them / above the diagonal
 };
@@ -479,6 +483,7 @@ __global__ __launch_bounds__(GW_THREADS) void k_group_waves(GroupTileArgs a) {
     __syncthreads();
     const unsigned long long lt_mask = (1ull << lane) - 1ull, le_mask = (2ull << lane) - 1ull;
     uint32_t n_rec = 0, n_grp = 0;
+    unsigned long long own_lookups = 0;
     // Tiles are dealt round-robin over the waves: the waves in flight read neighbouring tiles (a wave that owned a run of
     // consecutive tiles kept every wave on its own far-apart addresses, and the pass at a quarter of the streaming rate).
     for (uint32_t tile = gw; tile < tiles; tile += gridDim.x * GW_WAVES) {
@@ -608,16 +613,20 @@ __global__ __launch_bounds__(GW_THREADS) void k_group_waves(GroupTileArgs a) {
             } else if (live) {
                 const uint32_t cnt = po[j].y & ~HEAD_BIT;
                 if (po[j].y >> 31) a.post[u].y = cnt;                              // the bit has done its job
+                const bool mine = MODE == 1 || ((ins >> j) & 1u);
+                if (shared && mine) own_lookups += ge - gs;
                 if (r) {
                     const uint32_t at = tile_prefix + cnt_tile + (uint32_t) __popcll(rb & lt_mask);
                     const uint32_t start = MODE == 0 ? gs : u + 1;
                     a.key2[at] = po[j].x;
-                    a.tuples[at] = make_uint4(start, ge - start, cnt, ge - gs);     // {first posting, postings, own count, group size}
+                    if (a.pay8) a.pay8[at] = (unsigned long long) start | ((unsigned long long) ((ge - start) | (min(cnt, 1023u) << 22)) << 32);
+                    else a.tuples[at] = make_uint4(start, ge - start, cnt, ge - gs);     // {first posting, postings, own count, group size}
                 } else if (MODE == 1 || MODE == 2) {
-                    if (ge - gs >= 2 && u + 1 == ge && ((ins >> j) & 1u))
+                    if (!a.pay8 && ge - gs >= 2 && u + 1 == ge && mine)                  // (packed ranges: per-gene costs are made on demand)
                         atomicAdd(&a.cost[po[j].x], (unsigned long long) (ge - gs));
                 }
             }
+            if (PASS == 1 && a.head_bits && lane == 0) a.head_bits[(size_t) tile * GW_ROUNDS + j] = m[j];
             cnt_tile += (uint32_t) __popcll(rb);
             if (m[j]) pr = t0 + j * PDL_WAVE + 63u - (uint32_t) __clzll((long long) m[j]);
         }
@@ -637,7 +646,42 @@ __global__ __launch_bounds__(GW_THREADS) void k_group_waves(GroupTileArgs a) {
                 if (s_upper[i]) atomicAdd(&a.g_upper[i], s_upper[i]);
             }
         }
+    } else {
+        __shared__ unsigned long long s_own;
+        if (tid == 0) s_own = 0;
+        __syncthreads();
+#pragma unroll
+        for (int d = PDL_WAVE / 2; d > 0; d >>= 1) own_lookups += __shfl_xor(own_lookups, d, PDL_WAVE);
+        if (lane == 0 && own_lookups) atomicAdd(&s_own, own_lookups);
+        __syncthreads();
+        if (tid == 0 && s_own) atomicAdd(&a.counters[2], s_own);
     }
+}
+
+// Per-gene total_visited (library.cpp:327: every record of a group with >= 2 records adds the group size to its gene)
+// made on demand from the head bits the WRITE pass kept — only pdl_sequence_costs / pdl_genome_cost ask for it once the
+// ranges travel packed.  One thread per record; the extents come from word scans of the bit array.
+__global__ __launch_bounds__(256) void k_gene_costs_lazy(const uint2 *__restrict__ post, const unsigned long long *__restrict__ head_bits,
+                                                         uint32_t n, unsigned long long *__restrict__ cost) {
+    const uint32_t u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= n) return;
+    // word layout: tile t, round j -> word t * 16 + j holds records t * 1024 + j * 64 .. +63  == record >> 6
+    const uint32_t w = u >> 6, b = u & 63u, words = (n + 63) >> 6;
+    uint32_t gs, ge;
+    {
+        unsigned long long m = head_bits[w] & ((2ull << b) - 1ull);
+        uint32_t ww = w;
+        while (!m && ww > 0) m = head_bits[--ww];
+        gs = m ? ww * 64u + 63u - (uint32_t) __clzll((long long) m) : 0u;
+    }
+    {
+        unsigned long long m = b == 63 ? 0ull : head_bits[w] & ~((2ull << b) - 1ull);
+        uint32_t ww = w;
+        while (!m && ww + 1 < words) m = head_bits[++ww];
+        ge = m ? ww * 64u + (uint32_t) __ffsll((long long) m) - 1u : n;
+        if (ge > n) ge = n;
+    }
+    if (ge - gs >= 2) atomicAdd(&cost[post[u].x], (unsigned long long) (ge - gs));
 }
 
 // COUNT for the range modes, per-thread code (the mask arithmetic of k_group_waves keeps a wave's uniform values in
@@ -955,6 +999,7 @@ static void launch_group_tiles(pdl_ctx *c, const GroupTileArgs &a, uint32_t grid
 // d_scal[0]).  mode 0: whole groups for the shard's genes | 1: upper ranges, every gene | 2: upper ranges, the shard's genes.
 static void stage_ranges_and_costs(pdl_ctx *c, uint64_t bound, int mode, bool only_complexity) {
     hipStream_t st = c->stream;
+    c->costs_ready = true; c->ranges8 = nullptr;
     uint64_t *d_scal = c->scalars.as<uint64_t>();
     const uint64_t *d_u = d_scal + 0;
     uint2 *post = pdl_postings(c);
@@ -969,23 +1014,29 @@ static void stage_ranges_and_costs(pdl_ctx *c, uint64_t bound, int mode, bool on
         launch_group_tiles<0, 3, false, true>(c, ga, grid);
     } else {
         ev_begin(c, EV_SORT2);
-        // scratch layout: tuples uint4[bound] | v2a u32[bound] | k2b u32[bound] | v2b u32[bound]; key2 lives in vals_a (free after sort 1)
-        c->scratch.alloc(bound * (sizeof(uint4) + 3 * sizeof(uint32_t)));
+        // Ranges travel packed (8 bytes, carried through the gene sort as its payload: no gather afterwards) whenever a
+        // range sits right behind its own record (the upper modes) and a posting count fits 22 bits; else as 16-byte
+        // tuples fetched through the sorted positions.
+        const bool packed = mode != 0 && c->N < (1u << 22);
+        // scratch: packed   pay_a u64[bound] | pay_b u64[bound] | k2b u32[bound]
+        //          tuples   tuples uint4[bound] | v2a u32[bound] | k2b u32[bound] | v2b u32[bound];   key2 lives in vals_a (free after sort 1)
+        c->scratch.alloc(bound * (packed ? 2 * sizeof(uint64_t) + sizeof(uint32_t) : sizeof(uint4) + 3 * sizeof(uint32_t)));
         c->vals_a.alloc(bound * sizeof(uint32_t));
         uint4 *tuples = c->scratch.as<uint4>();
+        unsigned long long *pay_a = c->scratch.as<unsigned long long>(), *pay_b = pay_a + bound;
         uint32_t *k2a = c->vals_a.as<uint32_t>();
-        uint32_t *v2a = reinterpret_cast<uint32_t *>(tuples + bound);
-        uint32_t *k2b = v2a + bound;
-        uint32_t *v2b = k2b + bound;
+        uint32_t *v2a = packed ? nullptr : reinterpret_cast<uint32_t *>(tuples + bound);
+        uint32_t *k2b = packed ? reinterpret_cast<uint32_t *>(pay_b + bound) : v2a + bound;
+        uint32_t *v2b = packed ? nullptr : k2b + bound;
         if (mode != 1) {                    // the shard as gene-id intervals, when every genome's genes are consecutive ids (the usual .faa)
             std::vector<uint2> &iv = c->h_own_iv;
             iv.clear();
             bool contiguous = true;
             for (uint32_t g : c->dict_shard) {           // (ascending genome ids; genomes in first-seen order: ascending gene ids too)
-                const uint32_t b = c->h_genome_row_off[g], e = c->h_genome_row_off[g + 1];
-                if (b == e) continue;
-                const uint32_t first = c->h_genome_rows[b], last = c->h_genome_rows[e - 1];
-                if (last - first + 1 != e - b) { contiguous = false; break; }
+                const uint32_t b0 = c->h_genome_row_off[g], e0 = c->h_genome_row_off[g + 1];
+                if (b0 == e0) continue;
+                const uint32_t first = c->h_genome_rows[b0], last = c->h_genome_rows[e0 - 1];
+                if (last - first + 1 != e0 - b0) { contiguous = false; break; }
                 if (!iv.empty() && iv.back().y == first) iv.back().y = last + 1; else iv.push_back(make_uint2(first, last + 1));
             }
             if (contiguous) std::sort(iv.begin(), iv.end(), [](const uint2 &p, const uint2 &q) { return p.x < q.x; });
@@ -1009,6 +1060,11 @@ static void stage_ranges_and_costs(pdl_ctx *c, uint64_t bound, int mode, bool on
             ga.in_shard = c->seq_in_shard.as<uint8_t>();
         }
         ga.key2 = k2a; ga.tuples = tuples;
+        if (packed) {
+            ga.pay8 = pay_a;
+            c->head_bits.alloc(((bound + GW_TILE - 1) / GW_TILE) * GW_ROUNDS * sizeof(uint64_t));
+            ga.head_bits = c->head_bits.as<unsigned long long>();
+        }
         const uint64_t *d_us = d_scal + 2;       // ranges built = the total of the tile counts
         {
             const size_t dyn = (size_t) ga.n_own_iv * sizeof(uint2);
@@ -1035,14 +1091,22 @@ static void stage_ranges_and_costs(pdl_ctx *c, uint64_t bound, int mode, bool on
             rd.sync();
             n_sort = pn[0]; d_sort_n = nullptr;
         }
-        pdl_sort_pairs<uint32_t>(c, k2a, k2b, v2a, v2b, n_sort, seq_bits, true, d_sort_n);     // values = tuple positions; sorted pairs now in (k2b, v2b)
-        ev_end(c, EV_SORT2);
-
-        ev_begin(c, EV_RANGES);
-        c->ranges.alloc(std::max<uint64_t>(n_sort, 1) * sizeof(uint4));
         c->seq_off.alloc(((size_t) c->N + 1) * sizeof(uint32_t));
-        const uint32_t gblocks = (uint32_t) std::max<uint64_t>((n_sort + 255) / 256, 1);
-        hipLaunchKernelGGL(k_gather_ranges, dim3(gblocks), dim3(256), 0, st, v2b, k2b, tuples, d_us, c->ranges.as<uint4>(), c->cost.as<unsigned long long>());
+        if (packed) {
+            pdl_sort_pairs<uint32_t, unsigned long long>(c, k2a, k2b, pay_a, pay_b, n_sort, seq_bits, false, d_sort_n);   // sorted pairs now in (k2b, pay_b)
+            ev_end(c, EV_SORT2);
+            ev_begin(c, EV_RANGES);
+            c->ranges8 = reinterpret_cast<const uint2 *>(pay_b);       // gene major: the join reads them where the sort left them
+            c->costs_ready = false;
+        } else {
+            pdl_sort_pairs<uint32_t>(c, k2a, k2b, v2a, v2b, n_sort, seq_bits, true, d_sort_n);     // values = tuple positions; sorted pairs now in (k2b, v2b)
+            ev_end(c, EV_SORT2);
+            ev_begin(c, EV_RANGES);
+            c->ranges8 = nullptr;
+            c->ranges.alloc(std::max<uint64_t>(n_sort, 1) * sizeof(uint4));
+            const uint32_t gblocks = (uint32_t) std::max<uint64_t>((n_sort + 255) / 256, 1);
+            hipLaunchKernelGGL(k_gather_ranges, dim3(gblocks), dim3(256), 0, st, v2b, k2b, tuples, d_us, c->ranges.as<uint4>(), c->cost.as<unsigned long long>());
+        }
         hipLaunchKernelGGL(k_seq_offsets, dim3((c->N + 1 + 255) / 256), dim3(256), 0, st, k2b, d_us, c->N, c->seq_off.as<uint32_t>());
         PDL_HIP(hipGetLastError());
         ev_end(c, EV_RANGES);
@@ -1056,13 +1120,14 @@ static void stage_ranges_and_costs(pdl_ctx *c, uint64_t bound, int mode, bool on
                        reinterpret_cast<unsigned long long *>(d_scal + 8));
     PDL_HIP(hipGetLastError());
 
-    uint64_t tail[12] = {0};
+    uint64_t tail[12] = {0}, tail_own = 0;
     {
         PinRead rd(c);                       // one copy: the whole control block
         const uint64_t *pt = rd.add<uint64_t>(d_scal, PDL_CTL_GCOST + (size_t) c->G);
         rd.sync();
         c->h_genome_cost.assign(pt + PDL_CTL_GCOST, pt + PDL_CTL_GCOST + c->G);     // (a shard, one rank of several: its own genomes only)
         memcpy(tail, pt, sizeof(tail));
+        tail_own = pt[12];
     }
     c->U = tail[0];
     c->Ushared = tail[10];
@@ -1071,7 +1136,31 @@ static void stage_ranges_and_costs(pdl_ctx *c, uint64_t bound, int mode, bool on
     c->max_kseq = tail[7];
     c->min_kseq = tail[8] == 0 ? 1 : ~tail[8];
     c->P = 0;
-    for (uint64_t v : c->h_genome_cost) c->P += v;
+    if (c->costs_ready) for (uint64_t v : c->h_genome_cost) c->P += v;
+    else c->P = tail_own;                     // packed ranges: "Total cost" straight from the WRITE pass; per-gene / per-genome costs on demand
+}
+
+// cost[] (per gene) and h_genome_cost (per genome), when the build left them for later (packed ranges)
+void pdl_ensure_costs(pdl_ctx *c) {
+    if (c->costs_ready) return;
+    hipStream_t st = c->stream;
+    uint64_t *d_scal = c->scalars.as<uint64_t>();
+    PDL_HIP(hipMemsetAsync(c->cost.p, 0, (size_t) c->N * sizeof(uint64_t), st));
+    PDL_HIP(hipMemsetAsync(d_scal + PDL_CTL_GCOST, 0, (size_t) c->G * sizeof(uint64_t), st));
+    const uint32_t n = (uint32_t) c->U;
+    hipLaunchKernelGGL(k_gene_costs_lazy, dim3((n + 255) / 256), dim3(256), 0, st, pdl_postings(c), c->head_bits.as<unsigned long long>(), n,
+                       c->cost.as<unsigned long long>());
+    // per genome (the kseq statistics it also adds up go to scratch words)
+    hipLaunchKernelGGL(k_genome_cost, dim3(std::min<uint32_t>((c->N + 255) / 256, 128)), dim3(256), 0, st, c->cost.as<unsigned long long>(),
+                       c->kseq_len.as<uint32_t>(), c->d_gen, c->N, reinterpret_cast<unsigned long long *>(d_scal + PDL_CTL_GCOST),
+                       reinterpret_cast<unsigned long long *>(d_scal + 13), reinterpret_cast<unsigned long long *>(d_scal + 14),
+                       reinterpret_cast<unsigned long long *>(d_scal + 15));
+    PDL_HIP(hipGetLastError());
+    PinRead rd(c);
+    const uint64_t *pg = rd.add<uint64_t>(d_scal + PDL_CTL_GCOST, c->G);
+    rd.sync();
+    c->h_genome_cost.assign(pg, pg + c->G);
+    c->costs_ready = true;
 }
 
 template <class KeyT>

@@ -37,7 +37,9 @@ constexpr uint32_t CELL_CHUNK = 16384;                 // staging cells a workgr
 
 struct JoinArgs {
     const uint2 *post;
-    const uint4 *ranges;
+    const uint4 *ranges;           // {first posting, postings, own count, group size} per range, or ...
+    const uint2 *ranges8;          // ... (non-null) packed: {first posting, postings | min(own count, 1023) << 22}; the range sits right behind
+                                   //     its own record, so a count of 1023 or more is read from there; the group is named by its END
     const uint32_t *seq_off;
     const uint32_t *kseq_len;
     const uint32_t *genome_of;
@@ -209,6 +211,26 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
     // stage ranges [e0 + b0, e0 + b0 + nb) and return the number of lookups they hold
     auto stage = [&](uint32_t e0, uint32_t b0, uint32_t nb) -> uint32_t {
         uint32_t len[RPT], sum = 0;
+        if (a.ranges8) {                                     // (uniform) packed ranges: half the bytes, the group named by its end
+            uint2 rg8[RPT];
+#pragma unroll
+            for (uint32_t j = 0; j < RPT; j++) {             // the loads first, branch-free: they overlap
+                const uint32_t i = tid * RPT + j;
+                rg8[j] = a.ranges8[e0 + b0 + (i < nb ? i : nb - 1)];
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < RPT; j++) {
+                const uint32_t i = tid * RPT + j;
+                len[j] = 0;
+                if (i < nb) {
+                    const uint32_t l = rg8[j].y & 0x3fffffu;
+                    uint32_t own = rg8[j].y >> 22;
+                    if (own == 1023u) own = a.post[rg8[j].x - 1].y;      // (rare) the k-mer occurs >= 1023 times in this gene
+                    s_gm[i] = make_uint2(rg8[j].x, own); s_gsv[i] = rg8[j].x + l; len[j] = l;
+                }
+                sum += len[j];
+            }
+        } else {
         uint4 rgs[RPT];
 #pragma unroll
         for (uint32_t j = 0; j < RPT; j++) {                 // the loads first, branch-free: they overlap
@@ -224,6 +246,7 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
                 s_gm[i] = make_uint2(rg.x, rg.z); s_gsv[i] = rg.x + rg.y - rg.w; len[j] = rg.y;
             }
             sum += len[j];
+        }
         }
         // exclusive prefix over the workgroup with ONE barrier: wave scans, wave totals through LDS, and every thread adds
         // up the (at most 16) totals of the waves before its own — the staging costs two barriers per batch, not five
@@ -555,8 +578,19 @@ __global__ __launch_bounds__(HBM_THREADS) void k_join_hbm(JoinArgs a) {
         // one wave per range; the whole workgroup strides over the long ones implicitly via wave count
         const uint32_t wave = tid / PDL_WAVE, lane = tid % PDL_WAVE, nwaves = JOIN_THREADS / PDL_WAVE;
         for (uint32_t e = e0 + wave; e < e1; e += nwaves) {
-            const uint4 rg = a.ranges[e];                     // {first posting, postings, own count, group size}
-            const uint32_t finv = 0xffffffffu - (rg.x + rg.y - rg.w);   // group start
+            uint4 rg;                                         // {first posting, postings, own count, group size}
+            uint32_t group_key;                               // names the group in rank order: its start, or (packed ranges) its end
+            if (a.ranges8) {
+                const uint2 r8 = a.ranges8[e];
+                uint32_t own = r8.y >> 22;
+                if (own == 1023u) own = a.post[r8.x - 1].y;
+                rg = make_uint4(r8.x, r8.y & 0x3fffffu, own, 0u);
+                group_key = rg.x + rg.y;
+            } else {
+                rg = a.ranges[e];
+                group_key = rg.x + rg.y - rg.w;
+            }
+            const uint32_t finv = 0xffffffffu - group_key;
             for (uint32_t q = lane; q < rg.y; q += PDL_WAVE) {
                 const uint2 po = a.post[rg.x + q];
                 const uint32_t c = po.x;
@@ -1131,7 +1165,7 @@ static void score_alloc_cells(pdl_ctx *c, const ScorePlan &pl, unsigned long lon
 
 static JoinArgs join_args(pdl_ctx *c, const ScorePlan &pl) {
     JoinArgs a{};
-    a.post = pdl_postings(c); a.ranges = c->ranges.as<uint4>(); a.seq_off = c->seq_off.as<uint32_t>();
+    a.post = pdl_postings(c); a.ranges = c->ranges.as<uint4>(); a.ranges8 = c->ranges8; a.seq_off = c->seq_off.as<uint32_t>();
     a.kseq_len = c->kseq_len.as<uint32_t>(); a.genome_of = c->d_gen;
     a.task_rows = c->task_rows.as<uint32_t>(); a.task_lg = c->task_lg.as<uint32_t>();
     a.N = c->N; a.G = c->G; a.k = c->rp.k;
@@ -1294,7 +1328,8 @@ static void score_reset(pdl_ctx *c) {
     c->tm.emitted_cells = 0; c->tm.scored_rows = c->n_task_rows; c->tm.overflow_rows = 0; c->tm.join_launches = 0;
     c->tm.scored_lookups = 0; c->tm.walked_lookups = 0; c->tm.outbox_cells = c->tm.inbox_cells = 0;
     c->tm.dist_score_begin_ms = c->tm.dist_score_finish_ms = 0.f;
-    for (uint32_t i = 0; i < S; i++) c->tm.scored_lookups += c->h_genome_cost[c->shard[i]];
+    if (c->costs_ready) for (uint32_t i = 0; i < S; i++) c->tm.scored_lookups += c->h_genome_cost[c->shard[i]];
+    else c->tm.scored_lookups = c->P;         // (packed ranges: the total of this context's genomes, per-genome values on demand)
 }
 
 void pdl_run_score_all(pdl_ctx *c) {

@@ -68,14 +68,14 @@ struct RsOffsApply {
     __device__ void operator()(uint64_t i, uint32_t, uint32_t prefix) const { offs[i] = prefix; }
 };
 
-template <class KeyT>
-__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const KeyT *__restrict__ keys_in, const uint32_t *vals_in,
-                                                           KeyT *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint64_t n_bound,
+template <class KeyT, class ValT>
+__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const KeyT *__restrict__ keys_in, const ValT *vals_in,
+                                                           KeyT *__restrict__ keys_out, ValT *__restrict__ vals_out, uint64_t n_bound,
                                                            const uint64_t *d_n, uint32_t shift, uint32_t n_tiles, const uint32_t *__restrict__ offs) {
     const uint64_t n = scan_count(n_bound, d_n);
     if ((uint64_t) blockIdx.x * (RS_THREADS * RS_ROUNDS) >= n) return;       // (uniform) tile past the end
     __shared__ KeyT s_key[RS_TILE];
-    __shared__ uint32_t s_val[RS_TILE];
+    __shared__ ValT s_val[RS_TILE];
     __shared__ uint32_t s_cnt[RS_WAVES][RS_BINS];     // per wave: running count of each digit, then its base inside the tile
     __shared__ uint32_t s_tile_off[RS_BINS];          // start of each digit's run inside the tile
     __shared__ uint32_t s_goff[RS_BINS];              // global start of this tile's run of each digit
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const KeyT *__restric
     __syncthreads();
 
     KeyT key[RS_ROUNDS];
-    uint32_t val[RS_ROUNDS];
+    ValT val[RS_ROUNDS];
     uint16_t rank[RS_ROUNDS];          // position among the wave's elements of the same digit
     const unsigned long long below = (1ull << lane) - 1ull;
     // every load of the tile first, branch-free (clamped index): thirty-two loads in flight per lane.  Behind a branch or
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const KeyT *__restric
         }
     } else {                                         // the values are the positions 0, 1, 2, ...
 #pragma unroll
-        for (int j = 0; j < RS_ROUNDS; j++) val[j] = (uint32_t) (wave_base + (uint64_t) j * PDL_WAVE + lane);
+        for (int j = 0; j < RS_ROUNDS; j++) val[j] = (ValT) (wave_base + (uint64_t) j * PDL_WAVE + lane);
     }
 #pragma unroll
     for (int j = 0; j < RS_ROUNDS; j++) {
@@ -161,8 +161,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const KeyT *__restric
     }
 }
 
-template <class KeyT>
-void pdl_sort_pairs(pdl_ctx *c, KeyT *&keys_in, KeyT *&keys_out, uint32_t *&vals_in, uint32_t *&vals_out,
+template <class KeyT, class ValT>
+void pdl_sort_pairs(pdl_ctx *c, KeyT *&keys_in, KeyT *&keys_out, ValT *&vals_in, ValT *&vals_out,
                     uint64_t n, uint32_t end_bit, bool iota_values, const uint64_t *d_n) {
     if (n == 0) return;
     if (end_bit == 0) end_bit = 1;
@@ -178,8 +178,8 @@ void pdl_sort_pairs(pdl_ctx *c, KeyT *&keys_in, KeyT *&keys_out, uint32_t *&vals
         const uint32_t shift = p * 8;
         hipLaunchKernelGGL((k_rs_hist<KeyT>), dim3(n_tiles), dim3(RS_THREADS), 0, c->stream, keys_in, n, d_n, shift, n_tiles, counts);
         scan_and_apply(c, table, RsCountFlag{counts}, RsOffsApply{offs}, d_total);
-        hipLaunchKernelGGL((k_rs_scatter<KeyT>), dim3(n_tiles), dim3(RS_THREADS), 0, c->stream, keys_in,
-                           (p == 0 && iota_values) ? (const uint32_t *) nullptr : vals_in, keys_out, vals_out, n, d_n, shift, n_tiles, offs);
+        hipLaunchKernelGGL((k_rs_scatter<KeyT, ValT>), dim3(n_tiles), dim3(RS_THREADS), 0, c->stream, keys_in,
+                           (p == 0 && iota_values) ? (const ValT *) nullptr : vals_in, keys_out, vals_out, n, d_n, shift, n_tiles, offs);
         PDL_HIP(hipGetLastError());
         std::swap(keys_in, keys_out);
         std::swap(vals_in, vals_out);
@@ -190,5 +190,6 @@ void pdl_sort_pairs(pdl_ctx *c, KeyT *&keys_in, KeyT *&keys_out, uint32_t *&vals
     std::swap(vals_in, vals_out);
 }
 
-template void pdl_sort_pairs<uint32_t>(pdl_ctx *, uint32_t *&, uint32_t *&, uint32_t *&, uint32_t *&, uint64_t, uint32_t, bool, const uint64_t *);
-template void pdl_sort_pairs<uint64_t>(pdl_ctx *, uint64_t *&, uint64_t *&, uint32_t *&, uint32_t *&, uint64_t, uint32_t, bool, const uint64_t *);
+template void pdl_sort_pairs<uint32_t, uint32_t>(pdl_ctx *, uint32_t *&, uint32_t *&, uint32_t *&, uint32_t *&, uint64_t, uint32_t, bool, const uint64_t *);
+template void pdl_sort_pairs<uint64_t, uint32_t>(pdl_ctx *, uint64_t *&, uint64_t *&, uint32_t *&, uint32_t *&, uint64_t, uint32_t, bool, const uint64_t *);
+template void pdl_sort_pairs<uint32_t, unsigned long long>(pdl_ctx *, uint32_t *&, uint32_t *&, unsigned long long *&, unsigned long long *&, uint64_t, uint32_t, bool, const uint64_t *);

@@ -266,7 +266,13 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
             const uint32_t i = tid * RPT + j;
             s_cum[i] = i < nb ? ex : (i == nb ? total : 0xffffffffu);     // s_cum[nb] = total: > every flat index
             if (len[j]) {                                    // the range that holds a segment's first lookup registers itself
-                const uint32_t w_lo = seg ? (ex + seg - 1) / seg : 0;        // first w with w * seg >= ex
+                uint32_t w_lo = 0;                                           // first w with w * seg >= ex
+                if constexpr (NW <= 4) {                                     // (a few compares instead of an integer division per range)
+#pragma unroll
+                    for (uint32_t w = 0; w < NW; w++) w_lo += (uint32_t) (w * seg < ex);
+                } else {
+                    w_lo = seg ? (ex + seg - 1) / seg : 0;
+                }
                 for (uint32_t w = w_lo; w < NW && w * seg < ex + len[j]; w++) s_wstart[w] = make_uint2(i, ex);
             }
             ex += len[j];

@@ -64,6 +64,9 @@ void pdl_destroy(pdl_ctx *c) {
     if (c->pin) (void) hipHostFree(c->pin);
     if (c->mirror) (void) hipHostFree(c->mirror);
     if (c->edge_mirror) (void) hipHostFree(c->edge_mirror);
+    if (c->task_pin) (void) hipHostFree(c->task_pin);
+    if (c->gen_pin) (void) hipHostFree(c->gen_pin);
+    if (c->ev_gen) (void) hipEventDestroy(c->ev_gen);
     delete c;
 }
 
@@ -94,6 +97,32 @@ static void build_genome_layout(pdl_ctx *c) {
     for (uint32_t i = 0; i < N; i++) c->h_genome_rows[cur[c->h_genome_of[i]]++] = i;
 }
 
+// genome layout + what depends on the genome count (shard check)
+static void layout_and_shard(pdl_ctx *c) {
+    build_genome_layout(c);
+    c->dict_shard.clear();
+    if (c->shard_set) {
+        for (uint32_t g : c->shard)
+            if (g >= c->G) PDL_FAIL(PDL_ERR_ARGUMENT, "genome shard: id %u out of range (%u genomes)", g, c->G);
+        c->dict_shard = c->shard;            // posting-range lists are built for these genomes' genes only
+    }
+}
+
+}  // extern "C"   (C++ helpers of the other translation units)
+void pdl_input_arrived(pdl_ctx *c) {
+    PDL_HIP(hipEventSynchronize(c->ev_gen));
+    const uint64_t *ends = reinterpret_cast<const uint64_t *>(c->gen_pin + ((c->N + 1) & ~1u));
+    if (ends[0] != 0 || ends[1] != c->R)
+        PDL_FAIL(PDL_ERR_ARGUMENT, "offsets[0] = %llu, offsets[n] = %llu do not span the %llu residues", (unsigned long long) ends[0],
+                 (unsigned long long) ends[1], (unsigned long long) c->R);
+}
+void pdl_finish_layout(pdl_ctx *c) {
+    c->h_genome_of.assign(c->gen_pin, c->gen_pin + c->N);
+    c->layout_deferred = false;
+    layout_and_shard(c);
+}
+extern "C" {
+
 static int preprocess_common(pdl_ctx *c, uint32_t n, uint64_t n_res, int k, int only_complexity, pdl_cost *out_cost) {
     PDL_GUARD_BEGIN
     PDL_HIP(hipSetDevice(c->device));
@@ -102,14 +131,8 @@ static int preprocess_common(pdl_ctx *c, uint32_t n, uint64_t n_res, int k, int 
     c->U = c->Ushared = c->NG = c->P = c->M = 0;
     if (k <= 0) PDL_FAIL(PDL_ERR_KVALUE, "K value must be greater than 0.");
     if (n == 0) PDL_FAIL(PDL_ERR_EMPTY, "empty dataset");
-    build_genome_layout(c);
-    c->dict_shard.clear();
     if (c->dist) { c->shard.clear(); c->shard_set = false; c->dist = false; c->dist_stage = 0; }    // (a multi-GPU build's own deal does not carry over)
-    if (c->shard_set) {
-        for (uint32_t g : c->shard)
-            if (g >= c->G) PDL_FAIL(PDL_ERR_ARGUMENT, "genome shard: id %u out of range (%u genomes)", g, c->G);
-        c->dict_shard = c->shard;            // posting-range lists are built for these genomes' genes only
-    }
+    if (!c->layout_deferred) layout_and_shard(c);        // (device input: done behind the first kernels, pdl_finish_layout)
     pdl_run_preprocess(c, k, only_complexity != 0);
     c->preprocessed = true;
     fill_cost(c, out_cost);
@@ -163,9 +186,31 @@ int pdl_preprocess_device(pdl_ctx *c, const uint8_t *d_residues, const uint64_t 
     if (!d_offsets || !d_genome_of || (!d_residues && n_res)) PDL_FAIL(PDL_ERR_ARGUMENT, "null input pointer");
     if (((uintptr_t) d_residues & 15) != 0) PDL_FAIL(PDL_ERR_ARGUMENT, "d_residues must be 16-byte aligned");
     PDL_HIP(hipSetDevice(c->device));
-    adopt_device_input(c, d_residues, d_offsets, d_genome_of, n, n_res);
+    if (n == 0 || k <= 0) {
+        adopt_device_input(c, d_residues, d_offsets, d_genome_of, n, n_res);
+    } else {
+        // genome ids and the two ends of the offsets start their way to the host (pinned: a true asynchronous copy); the
+        // first kernels are queued behind them and the host builds the genome layout while those run
+        c->d_res = d_residues; c->d_off = d_offsets; c->d_gen = d_genome_of;
+        const size_t words = (((size_t) n + 1) & ~(size_t) 1) + 4;
+        if (c->gen_pin_words < words) {
+            if (c->gen_pin) (void) hipHostFree(c->gen_pin);
+            c->gen_pin = nullptr; c->gen_pin_words = 0;
+            PDL_HIP(hipHostMalloc((void **) &c->gen_pin, (words + words / 4) * sizeof(uint32_t), hipHostMallocDefault));
+            c->gen_pin_words = words + words / 4;
+        }
+        if (!c->ev_gen) PDL_HIP(hipEventCreateWithFlags(&c->ev_gen, hipEventDisableTiming));
+        uint64_t *ends = reinterpret_cast<uint64_t *>(c->gen_pin + (((size_t) n + 1) & ~(size_t) 1));
+        PDL_HIP(hipMemcpyAsync(ends, d_offsets, 8, hipMemcpyDeviceToHost, c->stream));
+        PDL_HIP(hipMemcpyAsync(ends + 1, d_offsets + n, 8, hipMemcpyDeviceToHost, c->stream));
+        PDL_HIP(hipMemcpyAsync(c->gen_pin, d_genome_of, (size_t) n * 4, hipMemcpyDeviceToHost, c->stream));
+        PDL_HIP(hipEventRecord(c->ev_gen, c->stream));
+        c->layout_deferred = true;
+    }
     PDL_GUARD_END(c)
-    return preprocess_common(c, n, n_res, k, only_complexity, out_cost);
+    const int rc = preprocess_common(c, n, n_res, k, only_complexity, out_cost);
+    c->layout_deferred = false;
+    return rc;
 }
 
 int pdl_genome_cost(const pdl_ctx *cc, uint32_t genome, uint64_t *out) {

@@ -75,6 +75,12 @@ struct DevBuf {
     DevBuf &operator=(const DevBuf &) = delete;
 };
 
+// a typed window into someone else's device allocation
+struct DevView {
+    void *p = nullptr;
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
 // ---- alphabet / rank parameters (library.cpp:56-64, 88-132) -----------------------------------
 struct RankParams {
     uint8_t rank_values[256];
@@ -104,6 +110,12 @@ struct pdl_ctx {
     const uint64_t *d_off = nullptr;
     const uint32_t *d_gen = nullptr;
     DevBuf in_res, in_off, in_gen;
+
+    // device-resident input: genome ids (and the two ends of the offsets) come to the host through this pinned buffer while the
+    // first kernels already run; the genome layout is built behind them (pdl_finish_layout)
+    uint32_t *gen_pin = nullptr; size_t gen_pin_words = 0;
+    hipEvent_t ev_gen = nullptr;
+    bool layout_deferred = false;
 
     bool preprocessed = false;
     bool only_complexity = false;
@@ -150,8 +162,11 @@ struct pdl_ctx {
     std::vector<int32_t> h_local_genome;      // [G] genome -> index in shard or -1
     std::vector<uint32_t> h_task_row_off;     // [shard+1] task position of each shard genome's first row
     std::vector<uint64_t> h_cell_off;         // [shard+1] first cell of each shard genome
-    DevBuf task_rows;     // u32 [n_task_rows] gene id of each task position
-    DevBuf task_lg;       // u32 [n_task_rows] shard-local genome index
+    // task layout on the device: one allocation, one upload from a pinned staging buffer (pdl_prepare_tasks)
+    DevBuf task_blob;
+    uint32_t *task_pin = nullptr; size_t task_pin_words = 0;
+    DevView task_rows;    // u32 [n_task_rows] gene id of each task position
+    DevView task_lg;      // u32 [n_task_rows] shard-local genome index
     DevBuf row_desc;      // uint4 [n_task_rows] {task position, gene, first range, ranges} in processing order
     DevBuf MS;            // f32 [n_task_rows][G]      max_genome_score rows
     DevBuf CM;            // f32 [shard][N]            max_genome_score_col per genome task
@@ -165,8 +180,9 @@ struct pdl_ctx {
     DevBuf glb_table;     // HBM tables of the overflow pass
     bool glb_clean = false;   // all-zero (k_join_hbm leaves them that way)
     DevBuf row_desc2;     // descriptors of the rows handed from tier 1 to tier 2
-    DevBuf st_src, taskpos_of, mirror_cnt, mirror_ref;   // mirror mode (see pdl_join.hip)
-    std::vector<uint32_t> h_task_rows_host, h_task_lg_host, h_taskpos_host, h_fin;
+    DevBuf st_src, mirror_cnt, mirror_ref;   // mirror mode (see pdl_join.hip)
+    DevView taskpos_of;                      // u32 [N] task position of every gene (0xffffffff: not a row of this context)
+    std::vector<uint32_t> h_fin;
     bool tasks_ready = false;  // task layout uploaded for the current shard
     DevBuf scratch2;      // small transient device scratch (interval histogram, per-genome lookups)
     DevBuf task_off;      // u32 [shard+1] task offsets | gathered cell offsets + 8 counters + cell total
@@ -198,7 +214,7 @@ struct pdl_ctx {
     std::vector<uint64_t> h_upper_cost;       // [G] lookups above the diagonal per genome (what a rank's join walks)
     std::vector<uint64_t> h_run_weights;      // [G] the same inside this rank's run of the dictionary (summed over ranks: the deal's weights)
     DevBuf owner_of_genome;                   // u32 [G]
-    DevBuf local_genome;                      // u32 [G] index in the shard, 0xffffffff for other ranks' genomes
+    DevView local_genome;                     // u32 [G] index in the shard, 0xffffffff for other ranks' genomes
     DevBuf outbox;                            // pdl_dist_cell [remote mirrored cells], grouped by destination rank
     DevBuf outbox_tab;                        // u32 [workgroups][world] counts, then offsets
     std::vector<uint64_t> h_outbox_counts;    // [world]
@@ -250,6 +266,8 @@ void pdl_run_dist_score_finish(pdl_ctx *c, const pdl_dist_cell *d_inbox, uint64_
 void pdl_prepare_tasks(pdl_ctx *c);
 void pdl_run_bbh_all(pdl_ctx *c);
 void pdl_ensure_costs(pdl_ctx *c);
+void pdl_input_arrived(pdl_ctx *c);      // deferred device input: waits for the genome ids / offset ends and checks them
+void pdl_finish_layout(pdl_ctx *c);      // ... then builds the genome layout on the host
 inline uint2 *pdl_postings(const pdl_ctx *c) { return c->post_ext ? c->post_ext : c->post.as<uint2>(); }
 
 // event helpers

@@ -887,24 +887,27 @@ static void stage_alphabet_and_lengths(pdl_ctx *c, int kvalue, bool only_complex
     if (kvalue <= 0) PDL_FAIL(PDL_ERR_KVALUE, "K value must be greater than 0.");
     // control block: scalars[16] | residue histogram[256] | per-genome cost[G] (+ [G] lookups above the diagonal, multi-GPU)
     // — one allocation, one clearing fill, one device->host copy whenever the host looks
-    const size_t ctl_words = PDL_CTL_GCOST + 2 * (size_t) c->G;
+    // (device input whose genome ids are still on their way to the host: G is not known yet, at most N)
+    const size_t ctl_words = PDL_CTL_GCOST + 2 * (size_t) (c->layout_deferred ? c->N : c->G);
     c->scalars.alloc(ctl_words * sizeof(uint64_t));
     uint64_t *d_scal = c->scalars.as<uint64_t>();
     PDL_HIP(hipMemsetAsync(d_scal, 0, ctl_words * sizeof(uint64_t), st));
 
     ev_begin(c, EV_HIST);
-    if (c->R) {
-        uint32_t blocks = (uint32_t) std::min<uint64_t>((c->R / 16 + HIST_THREADS - 1) / HIST_THREADS + 1, 256);
-        hipLaunchKernelGGL(k_hist, dim3(blocks), dim3(HIST_THREADS), 0, st, c->d_res, c->R,
-                           reinterpret_cast<unsigned long long *>(d_scal + PDL_CTL_HIST));
-    }
-    // K-len (independent of the histogram); its apply step also clears cost[], its total also lands in kmer_off[N]
+    // K-len (independent of the histogram, reads the offsets only); its apply step also clears cost[], its total also lands in kmer_off[N]
     c->kseq_len.alloc((size_t) c->N * sizeof(uint32_t));
     c->kmer_off.alloc(((size_t) c->N + 1) * sizeof(uint64_t));
     c->cost.alloc((size_t) c->N * sizeof(uint64_t));
     scan_and_apply(c, c->N, KseqFlag{c->d_off, (uint32_t) kvalue},
                    KseqApply{c->kseq_len.as<uint32_t>(), c->kmer_off.as<uint64_t>(), c->cost.as<unsigned long long>(), c->d_off, c->R,
                              reinterpret_cast<unsigned long long *>(d_scal + 3)}, d_scal + 5, c->kmer_off.as<uint64_t>() + c->N);
+    if (c->layout_deferred) pdl_input_arrived(c);        // offsets[0] = 0 and offsets[N] = R checked before anything indexes residues
+    if (c->R) {
+        uint32_t blocks = (uint32_t) std::min<uint64_t>((c->R / 16 + HIST_THREADS - 1) / HIST_THREADS + 1, 256);
+        hipLaunchKernelGGL(k_hist, dim3(blocks), dim3(HIST_THREADS), 0, st, c->d_res, c->R,
+                           reinterpret_cast<unsigned long long *>(d_scal + PDL_CTL_HIST));
+    }
+    if (c->layout_deferred) pdl_finish_layout(c);        // host work (genes by genome) while the histogram runs
     uint64_t counters[256];
     uint64_t M = 0, bad = 0;
     {

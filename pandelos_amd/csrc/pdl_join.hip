@@ -1036,34 +1036,37 @@ void pdl_prepare_tasks(pdl_ctx *c) {
     c->h_task_row_off.assign(S + 1, 0);
     uint32_t n_rows = 0;
     for (uint32_t i = 0; i < S; i++) n_rows += c->h_genome_row_off[c->shard[i] + 1] - c->h_genome_row_off[c->shard[i]];
-    c->h_task_rows_host.resize(n_rows);
-    c->h_task_lg_host.resize(n_rows);
+    // one pinned staging buffer, filled in place: task_rows[n_rows] | task_lg[n_rows] | taskpos_of[N] | local_genome[G]
+    // -> ONE upload (separate copies from pageable vectors were five staged transfers with the device idle in between)
+    const size_t words = 2 * (size_t) n_rows + N + G;
+    if (c->task_pin_words < words) {
+        if (c->task_pin) (void) hipHostFree(c->task_pin);
+        c->task_pin = nullptr; c->task_pin_words = 0;
+        PDL_HIP(hipHostMalloc((void **) &c->task_pin, (words + words / 4 + 16) * sizeof(uint32_t), hipHostMallocDefault));
+        c->task_pin_words = words + words / 4 + 16;
+    }
+    uint32_t *h_rows = c->task_pin, *h_lg = h_rows + n_rows, *h_pos = h_lg + n_rows, *h_loc = h_pos + N;
+    for (uint32_t i = 0; i < N; i++) h_pos[i] = 0xffffffffu;
     uint32_t p = 0;
     for (uint32_t i = 0; i < S; i++) {
         const uint32_t g = c->shard[i];
         c->h_local_genome[g] = (int32_t) i;
         c->h_task_row_off[i] = p;
-        for (uint32_t j = c->h_genome_row_off[g]; j < c->h_genome_row_off[g + 1]; j++) { c->h_task_rows_host[p] = c->h_genome_rows[j]; c->h_task_lg_host[p] = i; p++; }
+        for (uint32_t j = c->h_genome_row_off[g]; j < c->h_genome_row_off[g + 1]; j++) { const uint32_t gene = c->h_genome_rows[j]; h_rows[p] = gene; h_lg[p] = i; h_pos[gene] = p; p++; }
     }
+    for (uint32_t g = 0; g < G; g++) h_loc[g] = (uint32_t) c->h_local_genome[g];       // (int32 -1 reads as 0xffffffff)
     c->h_task_row_off[S] = n_rows;
     c->n_task_rows = n_rows;
     c->tasks_ready = true;
+    c->task_blob.alloc(words * sizeof(uint32_t) + 16);
+    PDL_HIP(hipMemcpyAsync(c->task_blob.p, c->task_pin, words * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    uint32_t *d = c->task_blob.as<uint32_t>();
+    c->task_rows.p = d; c->task_lg.p = d + n_rows; c->taskpos_of.p = d + 2 * (size_t) n_rows; c->local_genome.p = d + 2 * (size_t) n_rows + N;
     if (c->dist) {            // genome -> rank, for the cell exchange
         c->owner_of_genome.alloc((size_t) G * 4);
         PDL_HIP(hipMemcpyAsync(c->owner_of_genome.p, c->h_owner.data(), (size_t) G * 4, hipMemcpyHostToDevice, st));
     }
-    {   // every gene's task position (0xffffffff: not a row of this context) and every genome's CM row: mirror mode, K-bbh
-        c->h_taskpos_host.assign((size_t) N, 0xffffffffu);
-        for (uint32_t q = 0; q < n_rows; q++) c->h_taskpos_host[c->h_task_rows_host[q]] = q;
-        c->taskpos_of.alloc((size_t) N * 4);
-        PDL_HIP(hipMemcpyAsync(c->taskpos_of.p, c->h_taskpos_host.data(), (size_t) N * 4, hipMemcpyHostToDevice, st));
-        c->local_genome.alloc((size_t) G * 4);      // (int32 -1 reads as 0xffffffff)
-        PDL_HIP(hipMemcpyAsync(c->local_genome.p, c->h_local_genome.data(), (size_t) G * 4, hipMemcpyHostToDevice, st));
-    }
     if (n_rows == 0) return;
-    c->task_rows.alloc((size_t) n_rows * 4); c->task_lg.alloc((size_t) n_rows * 4);
-    PDL_HIP(hipMemcpyAsync(c->task_rows.p, c->h_task_rows_host.data(), (size_t) n_rows * 4, hipMemcpyHostToDevice, st));
-    PDL_HIP(hipMemcpyAsync(c->task_lg.p, c->h_task_lg_host.data(), (size_t) n_rows * 4, hipMemcpyHostToDevice, st));
     c->task_off.alloc((size_t) (S + 1) * 8 + 64);      // task offsets | gathered cell offsets + 8 counters + cell total
     PDL_HIP(hipMemcpyAsync(c->task_off.p, c->h_task_row_off.data(), (size_t) (S + 1) * 4, hipMemcpyHostToDevice, st));
 }

@@ -101,9 +101,10 @@ def launch_ranks(args) -> int:
 class Runner:
     """One rank's view of the job: device-resident inputs of a workload and the step function."""
 
-    def __init__(self, torch, dev, stream, n_gpus, rank, on_device_collectives):
+    def __init__(self, torch, dev, stream, n_gpus, rank, on_device_collectives, distributed=None):
         self.torch, self.dev, self.stream = torch, dev, stream
         self.n_gpus, self.rank, self.on_dev = n_gpus, rank, on_device_collectives
+        self.distributed = (n_gpus > 1) if distributed is None else distributed
         self.options = []
 
     def load(self, gs, k):
@@ -120,7 +121,7 @@ class Runner:
         for name, value in self.options:
             self.nat.set_option(name, value)
         self.dp = None
-        if self.n_gpus > 1:
+        if self.distributed:
             from pandelos_amd.distributed import DistributedPangenes
             self.dp = DistributedPangenes(self.nat, self.dev, self.on_dev)
 
@@ -134,7 +135,7 @@ class Runner:
             self.dp.score_all()
 
     def sync(self):
-        if self.n_gpus > 1:
+        if self.distributed:
             import torch.distributed as dist
             dist.barrier()
         self.torch.cuda.synchronize()
@@ -226,7 +227,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # (PDL_BENCH_FORCE_DIST=1 under a one-rank torchrun: the N > 1 code path, RCCL calls included, with a group of one)
+    distributed = world > 1 or os.environ.get("PDL_BENCH_FORCE_DIST") == "1"
     # PDL_BENCH_BACKEND=gloo + PDL_BENCH_ONE_DEVICE=1 rehearse the N > 1 flow on a one-GPU box (every rank on cuda:0,
     # exchanges staged through host tensors); the driver's runs use RCCL ("nccl"), one rank per GPU.
     backend = os.environ.get("PDL_BENCH_BACKEND", "nccl")
@@ -242,7 +244,7 @@ def main():
     n_gpus = world if distributed else 1
     coll_dev = dev if backend == "nccl" else None      # where the scalar collectives live
     stream = torch.cuda.current_stream().cuda_stream
-    run = Runner(torch, dev, stream, n_gpus, rank, backend == "nccl")
+    run = Runner(torch, dev, stream, n_gpus, rank, backend == "nccl", distributed)
     run.options = [(o.split("=")[0], int(o.split("=")[1])) for o in args.option]
 
     # ---- workload -----------------------------------------------------------------------------------

@@ -93,7 +93,7 @@ def test_canonical_order_and_tiny_staging_under_sharding():
     lr.close()
 
 
-@pytest.mark.parametrize("seed", list(range(5000, 5020)))
+@pytest.mark.parametrize("seed", list(range(5000, 5000 + int(os.environ.get("PDL_FUZZ_SEEDS_DIST", "20")))))   # widen with PDL_FUZZ_SEEDS_DIST=N
 def test_random_sets_sharded_match_the_oracle(seed):
     from oracle import binding as ob
     from tests.test_gpu_fuzz import _random_set
@@ -117,18 +117,22 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _rank_main(rank, world, port, name, out):
+def _rank_main(rank, world, port, name, out, backend="gloo"):
     import torch
     import torch.distributed as dist
     from pandelos_amd.distributed import DistributedPangenes
     from pandelos_amd.pangene_native import PangeneNative
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         res, off, gen, k, d = H.load_large(name)
         t = _device_inputs(res, off, gen)
-        dp = DistributedPangenes(PangeneNative.open(), torch.device("cuda", 0), device_collectives=False)
+        dp = DistributedPangenes(PangeneNative.open(), torch.device("cuda", 0), device_collectives=(backend == "nccl"))
         dp.preprocess(k, *t, len(gen), len(res))
         total_cost = dp.total_cost()
         dp.score_all()
@@ -144,14 +148,18 @@ def _rank_main(rank, world, port, name, out):
 
 
 @pytest.mark.timeout(600)
-def test_two_processes_over_torch_distributed_reproduce_the_digest():
+@pytest.mark.parametrize("backend,world", [("gloo", 2), ("nccl", 1)])
+def test_processes_over_torch_distributed_reproduce_the_digest(backend, world):
+    """gloo: two ranks sharing cuda:0, exchanges staged through the host.  nccl: RCCL takes one rank per device, so on a
+    one-GPU box this is a group of ONE — still the device-tensor branch of every exchange (all-gather of the run sizes,
+    the cell counts and cells through all_to_all_single, the cost all-reduce) running through RCCL for real."""
     import torch.multiprocessing as mp
     name = "synth_8x300x200_k4_div25"
     d = H.DIGESTS[name]
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, name, out)) for r in range(2)]
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, name, out, backend)) for r in range(world)]
     for p in procs:
         p.start()
     import queue
@@ -161,9 +169,9 @@ def test_two_processes_over_torch_distributed_reproduce_the_digest():
             got.append(out.get(timeout=0.5))
         except queue.Empty:
             assert all(p.is_alive() or p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
-        if len(got) == 2:
+        if len(got) == world:
             break
-    assert len(got) == 2
+    assert len(got) == world
     for p in procs:
         p.join(60)
         assert p.exitcode == 0

@@ -767,6 +767,215 @@ __global__ __launch_bounds__(GW_THREADS) void k_range_count(GroupTileArgs a) {
     if (tid < 2 && s_red[tid]) atomicAdd(&a.counters[tid], (unsigned long long) s_red[tid]);
 }
 
+// ---- the range tuples sorted by gene without being written in record order first ------------------------------------------
+// (upper ranges for every gene, packed: the single-GPU build.)  The first radix pass of the gene sort reads what the WRITE
+// pass has just written; here the kernel that BUILDS the tuples is that pass: a workgroup takes PDL_RADIX_TILE = 4 tiles of
+// records, k_range_count_hist has counted its tuples by the low byte of their gene (the pass's histogram; a record that gets
+// no range is simply not there), the scan of those counts says where every (block, byte) run starts, and k_range_scatter
+// makes the tuples as k_group_waves<WRITE> does and files them as k_rs_scatter does (ballot ranks, digit-sorted in LDS,
+// coalesced runs out).  Saves the tuples' trip through HBM (12 B written + 16 B read per range) and three launches.
+static_assert(GW_WAVES * GW_TILE == (int) PDL_RADIX_TILE && GW_THREADS == (int) PDL_RADIX_BINS, "a workgroup's four tiles are one tile of the radix pass");
+__global__ __launch_bounds__(GW_THREADS) void k_range_count_hist(GroupTileArgs a, uint32_t n_tiles4, uint32_t *__restrict__ counts) {
+    __shared__ uint32_t s_h[PDL_RADIX_BINS];
+    __shared__ uint32_t s_red[2];
+    const uint32_t tid = threadIdx.x, lane = tid & (PDL_WAVE - 1), wave = tid / PDL_WAVE;
+    const uint32_t n = (uint32_t) scan_count(a.n_bound, a.d_n);
+    if (tid < 2) s_red[tid] = 0;
+    uint32_t n_rec = 0, n_grp = 0;
+    for (uint32_t blk = blockIdx.x; blk < n_tiles4; blk += gridDim.x) {       // (uniform loop: barriers inside)
+        s_h[tid] = 0;
+        __syncthreads();
+        const uint32_t tile = blk * GW_WAVES + wave, t0 = tile * GW_TILE;
+        if (t0 < n) {                                     // (wave-uniform)
+            uint2 po[GW_ROUNDS];
+            uint32_t ynext[GW_ROUNDS];
+#pragma unroll
+            for (int j = 0; j < GW_ROUNDS; j++) {        // all loads first, branch-free
+                const uint32_t u = t0 + j * PDL_WAVE + lane;
+                po[j] = a.post[u < n ? u : n - 1];
+                ynext[j] = a.post[u + 1 < n ? u + 1 : n - 1].y;
+            }
+            uint32_t cnt = 0, first_h = GT_NONE, last_h = 0, any_h = 0;
+#pragma unroll
+            for (int j = 0; j < GW_ROUNDS; j++) {
+                const uint32_t u = t0 + j * PDL_WAVE + lane;
+                const bool live = u < n;
+                const bool head = live && (po[j].y >> 31);
+                const bool next_head = u + 1 >= n || (ynext[j] >> 31);
+                const bool r = live && !next_head;
+                if (r) atomicAdd(&s_h[po[j].x & (PDL_RADIX_BINS - 1)], 1u);
+                cnt += r;
+                n_rec += live && !(head && next_head); n_grp += head && !next_head;
+                if (head) { first_h = min(first_h, u); last_h = max(last_h, u); any_h = 1; }
+            }
+#pragma unroll
+            for (int d = PDL_WAVE / 2; d > 0; d >>= 1) {
+                cnt += __shfl_xor(cnt, d, PDL_WAVE);
+                first_h = min(first_h, (uint32_t) __shfl_xor((int) first_h, d, PDL_WAVE));
+                last_h = max(last_h, (uint32_t) __shfl_xor((int) last_h, d, PDL_WAVE));
+                any_h |= (uint32_t) __shfl_xor((int) any_h, d, PDL_WAVE);
+            }
+            if (lane == 0) { a.tile_sums[tile] = cnt; a.th_first[tile] = first_h; a.th_last[tile] = any_h ? last_h : GT_NONE; }
+        }
+        __syncthreads();
+        counts[(size_t) tid * n_tiles4 + blk] = s_h[tid];
+    }
+#pragma unroll
+    for (int d = PDL_WAVE / 2; d > 0; d >>= 1) { n_rec += __shfl_xor(n_rec, d, PDL_WAVE); n_grp += __shfl_xor(n_grp, d, PDL_WAVE); }
+    if (lane == 0) { atomicAdd(&s_red[0], n_rec); atomicAdd(&s_red[1], n_grp); }
+    __syncthreads();
+    if (tid < 2 && s_red[tid]) atomicAdd(&a.counters[tid], (unsigned long long) s_red[tid]);
+}
+
+__global__ __launch_bounds__(GW_THREADS) void k_range_scatter(GroupTileArgs a, uint32_t n_tiles4, const uint32_t *__restrict__ offs,
+                                                              uint32_t *__restrict__ keys_out, unsigned long long *__restrict__ vals_out) {
+    const uint32_t n = (uint32_t) scan_count(a.n_bound, a.d_n);
+    if ((uint64_t) blockIdx.x * PDL_RADIX_TILE >= n) return;               // (uniform) block past the end
+    __shared__ uint32_t s_key[PDL_RADIX_TILE];
+    __shared__ unsigned long long s_val[PDL_RADIX_TILE];
+    __shared__ uint16_t s_cnt[GW_WAVES][PDL_RADIX_BINS];   // per wave: running count of each byte value, then its base inside the block (16-bit: three workgroups per CU)
+    __shared__ uint32_t s_tile_off[PDL_RADIX_BINS];
+    __shared__ uint32_t s_goff[PDL_RADIX_BINS];
+    __shared__ uint32_t s_wsum[17];
+    __shared__ unsigned long long s_own;
+    const uint32_t tid = threadIdx.x, lane = tid & (PDL_WAVE - 1), wave = tid / PDL_WAVE;
+    const uint32_t tiles = (n + GW_TILE - 1) / GW_TILE;
+    const uint32_t tile = blockIdx.x * GW_WAVES + wave, t0 = tile * GW_TILE, t1 = min(t0 + (uint32_t) GW_TILE, n);
+    const bool active = tile < tiles;                    // (wave-uniform; the last block may hold fewer than four tiles)
+    for (int w = 0; w < GW_WAVES; w++) s_cnt[w][tid] = 0;
+    s_goff[tid] = offs[(size_t) tid * n_tiles4 + blockIdx.x];
+    if (tid == 0) s_own = 0;
+    __syncthreads();
+
+    const unsigned long long lt_mask = (1ull << lane) - 1ull, le_mask = (2ull << lane) - 1ull;
+    uint2 po[GW_ROUNDS];
+    unsigned long long val[GW_ROUNDS];
+    uint16_t rank[GW_ROUNDS];
+    uint32_t rbits = 0;                                  // bit j: this lane's record of round j gets a range
+    unsigned long long own_lookups = 0;
+#pragma unroll
+    for (int j = 0; j < GW_ROUNDS; j++) {                // all loads first, branch-free
+        const uint32_t u = t0 + j * PDL_WAVE + lane;
+        po[j] = a.post[u < n ? u : n - 1];
+    }
+    if (active) {
+        // the nearest tiles before / after with a head, 64 tiles per look (the COUNT pass's per-tile heads: other
+        // workgroups may have removed their head bits already)
+        const uint32_t hb = lane < tile ? a.th_last[tile - 1 - lane] : GT_NONE;
+        const uint32_t ha = tile + 1 + lane < tiles ? a.th_first[tile + 1 + lane] : GT_NONE;
+        unsigned long long m[GW_ROUNDS];
+#pragma unroll
+        for (int j = 0; j < GW_ROUNDS; j++) m[j] = __ballot(t0 + j * PDL_WAVE + lane < n && (po[j].y >> 31));
+        uint32_t before = t0;
+        if (!(m[0] & 1ull)) {                            // (uniform) the tile starts inside a group
+            unsigned long long hm = __ballot(hb != GT_NONE);
+            if (hm) before = (uint32_t) __shfl((int) hb, __ffsll((long long) hm) - 1, PDL_WAVE);
+            else {
+                before = 0;
+                for (uint32_t hi = tile >= PDL_WAVE ? tile - PDL_WAVE : 0; hi > 0;) {
+                    const uint32_t base = hi >= PDL_WAVE ? hi - PDL_WAVE : 0, idx = base + lane;
+                    const uint32_t v = idx < hi ? a.th_last[idx] : GT_NONE;
+                    hm = __ballot(v != GT_NONE);
+                    if (hm) { before = (uint32_t) __shfl((int) v, 63 - __clzll((long long) hm), PDL_WAVE); break; }
+                    hi = base;
+                }
+            }
+        }
+        uint32_t after;
+        {
+            unsigned long long hm = __ballot(ha != GT_NONE);
+            if (hm) after = (uint32_t) __shfl((int) ha, __ffsll((long long) hm) - 1, PDL_WAVE);
+            else {
+                after = n;
+                for (uint32_t lo = tile + 1 + PDL_WAVE; lo < tiles; lo += PDL_WAVE) {
+                    const uint32_t idx = lo + lane;
+                    const uint32_t v = idx < tiles ? a.th_first[idx] : GT_NONE;
+                    hm = __ballot(v != GT_NONE);
+                    if (hm) { after = (uint32_t) __shfl((int) v, __ffsll((long long) hm) - 1, PDL_WAVE); break; }
+                }
+            }
+        }
+        before = (uint32_t) __builtin_amdgcn_readfirstlane((int) before);
+        after = (uint32_t) __builtin_amdgcn_readfirstlane((int) after);
+        uint32_t nextr[GW_ROUNDS];
+        uint32_t nx = after;
+#pragma unroll
+        for (int j = GW_ROUNDS - 1; j >= 0; j--) {
+            nextr[j] = nx;
+            if (m[j]) nx = t0 + j * PDL_WAVE + (uint32_t) __ffsll((long long) m[j]) - 1u;
+        }
+        uint32_t pr = before;
+#pragma unroll
+        for (int j = 0; j < GW_ROUNDS; j++) {
+            const uint32_t u = t0 + j * PDL_WAVE + lane;
+            const unsigned long long at_or_below = m[j] & le_mask, above = m[j] & ~le_mask;
+            const uint32_t gs = at_or_below ? t0 + j * PDL_WAVE + 63u - (uint32_t) __clzll((long long) at_or_below) : pr;
+            const uint32_t ge = above ? t0 + j * PDL_WAVE + (uint32_t) __ffsll((long long) above) - 1u : nextr[j];
+            const bool live = u < t1;
+            const bool shared = live && ge - gs >= 2;
+            const bool r = shared && u + 1 < ge;         // the last member of a group has nothing above it
+            const uint32_t cnt = po[j].y & ~HEAD_BIT;
+            if (live && (po[j].y >> 31)) a.post[u].y = cnt;                    // the bit has done its job
+            if (shared) own_lookups += ge - gs;
+            val[j] = (unsigned long long) (u + 1) | ((unsigned long long) ((ge - u - 1) | (min(cnt, 1023u) << 22)) << 32);
+            rbits |= (uint32_t) r << j;
+            if (lane == 0) a.head_bits[(size_t) tile * GW_ROUNDS + j] = m[j];
+            if (m[j]) pr = t0 + j * PDL_WAVE + 63u - (uint32_t) __clzll((long long) m[j]);
+        }
+    }
+    // ---- the radix pass on the low byte of the gene (k_rs_scatter's ranking; an element is a record with a range) ----------
+#pragma unroll
+    for (int j = 0; j < GW_ROUNDS; j++) {
+        const bool valid = (rbits >> j) & 1u;
+        const uint32_t d = po[j].x & (PDL_RADIX_BINS - 1);
+        unsigned long long same = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const unsigned long long mb = __ballot((d >> b) & 1u);
+            same &= ((d >> b) & 1u) ? mb : ~mb;
+        }
+        const uint32_t seen = s_cnt[wave][d];                       // earlier rounds (own wave only: no race)
+        rank[j] = (uint16_t) (seen + (uint32_t) __popcll(same & lt_mask));
+        if (valid && (same & lt_mask) == 0) s_cnt[wave][d] = (uint16_t) (seen + (uint32_t) __popcll(same));      // lowest lane of the set
+    }
+    __syncthreads();
+    uint32_t tot = 0;
+    uint32_t wcnt[GW_WAVES];
+#pragma unroll
+    for (int w = 0; w < GW_WAVES; w++) { wcnt[w] = s_cnt[w][tid]; tot += wcnt[w]; }
+    uint32_t tile_total;
+    const uint32_t ex = block_exclusive_scan_u32(tot, s_wsum, tile_total);
+    s_tile_off[tid] = ex;
+    uint32_t run = ex;
+#pragma unroll
+    for (int w = 0; w < GW_WAVES; w++) { s_cnt[w][tid] = (uint16_t) run; run += wcnt[w]; }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < GW_ROUNDS; j++) {
+        if ((rbits >> j) & 1u) {
+            const uint32_t lp = s_cnt[wave][po[j].x & (PDL_RADIX_BINS - 1)] + rank[j];
+            s_key[lp] = po[j].x;
+            s_val[lp] = val[j];
+        }
+    }
+#pragma unroll
+    for (int d = PDL_WAVE / 2; d > 0; d >>= 1) own_lookups += __shfl_xor(own_lookups, d, PDL_WAVE);
+    if (lane == 0 && own_lookups) atomicAdd(&s_own, own_lookups);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < GW_ROUNDS; j++) {
+        const uint32_t e = j * GW_THREADS + tid;                     // coalesced over the digit-sorted block
+        if (e < tile_total) {
+            const uint32_t k = s_key[e];
+            const uint32_t d = k & (PDL_RADIX_BINS - 1);
+            const uint64_t dst = (uint64_t) s_goff[d] + (e - s_tile_off[d]);
+            keys_out[dst] = k;
+            vals_out[dst] = s_val[e];
+        }
+    }
+    if (tid == 0 && s_own) atomicAdd(&a.counters[2], s_own);
+}
+
 // Between the passes: tile_sums[t] (ranges of tile t) becomes the count of the tiles before t inside its block of 64 tiles,
 // chunk_sums[b] the block's total (scanned next); one wave per block.
 __global__ __launch_bounds__(256) void k_tile_prefix(uint32_t *__restrict__ tile_sums, const uint64_t *d_n, uint64_t n_bound,
@@ -1069,6 +1278,22 @@ static void stage_ranges_and_costs(pdl_ctx *c, uint64_t bound, int mode, bool on
             ga.head_bits = c->head_bits.as<unsigned long long>();
         }
         const uint64_t *d_us = d_scal + 2;       // ranges built = the total of the tile counts
+        // single-GPU build with packed ranges: the tuples are filed by the low byte of their gene by the kernel that makes
+        // them (the first pass of the gene sort without a trip through HBM in between)
+        const bool fused = mode == 1 && packed;
+        if (fused) {
+            const uint32_t n_tiles4 = (uint32_t) ((bound + PDL_RADIX_TILE - 1) / PDL_RADIX_TILE);
+            const size_t table = (size_t) PDL_RADIX_BINS * n_tiles4, tiles = (bound + GW_TILE - 1) / GW_TILE;
+            // (the scan below uses scan_tmp: the per-tile heads move next to the radix tables)
+            c->sort_tmp.alloc((2 * table + 3 * tiles + 1) * sizeof(uint32_t));
+            uint32_t *counts = c->sort_tmp.as<uint32_t>(), *offs = counts + table;
+            ga.tile_sums = offs + table; ga.th_first = ga.tile_sums + tiles; ga.th_last = ga.th_first + tiles; ga.chunk_sums = nullptr;
+            const uint32_t grid4 = std::max<uint32_t>(1, std::min<uint32_t>(n_tiles4, (uint32_t) c->cus * 8));
+            hipLaunchKernelGGL(k_range_count_hist, dim3(grid4), dim3(GW_THREADS), 0, st, ga, n_tiles4, counts);
+            pdl_radix_offsets(c, counts, offs, n_tiles4, d_scal + 2);
+            hipLaunchKernelGGL(k_range_scatter, dim3(n_tiles4), dim3(GW_THREADS), 0, st, ga, n_tiles4, offs, k2b, pay_b);
+            PDL_HIP(hipGetLastError());
+        } else {
         {
             const size_t dyn = (size_t) ga.n_own_iv * sizeof(uint2);
             if (mode == 1) hipLaunchKernelGGL(k_range_count<1>, dim3(grid), dim3(GW_THREADS), 0, st, ga);
@@ -1081,6 +1306,7 @@ static void stage_ranges_and_costs(pdl_ctx *c, uint64_t bound, int mode, bool on
         if (mode == 1) launch_group_tiles<1, 1, false, false>(c, ga, grid);
         else if (mode == 2) launch_group_tiles<1, 2, false, false>(c, ga, grid);
         else launch_group_tiles<1, 0, false, false>(c, ga, grid);
+        }
         c->upper_only = mode != 0;
         const uint32_t seq_bits = std::max<uint32_t>(1, bit_length64(c->N ? c->N - 1 : 0));
         // One GPU: the range count stays on the device, the kernels behind it are sized for the bound.  Multi-GPU: a rank
@@ -1096,6 +1322,10 @@ static void stage_ranges_and_costs(pdl_ctx *c, uint64_t bound, int mode, bool on
         }
         c->seq_off.alloc(((size_t) c->N + 1) * sizeof(uint32_t));
         if (packed) {
+            if (fused) {                     // pass 1 is done: (k2b, pay_b) hold its output, the remaining passes go on from there
+                std::swap(k2a, k2b); std::swap(pay_a, pay_b);
+                pdl_sort_pairs<uint32_t, unsigned long long>(c, k2a, k2b, pay_a, pay_b, n_sort, seq_bits, false, d_sort_n, 8);
+            } else
             pdl_sort_pairs<uint32_t, unsigned long long>(c, k2a, k2b, pay_a, pay_b, n_sort, seq_bits, false, d_sort_n);   // sorted pairs now in (k2b, pay_b)
             ev_end(c, EV_SORT2);
             ev_begin(c, EV_RANGES);

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const KeyT *__restric
 
 template <class KeyT, class ValT>
 void pdl_sort_pairs(pdl_ctx *c, KeyT *&keys_in, KeyT *&keys_out, ValT *&vals_in, ValT *&vals_out,
-                    uint64_t n, uint32_t end_bit, bool iota_values, const uint64_t *d_n) {
+                    uint64_t n, uint32_t end_bit, bool iota_values, const uint64_t *d_n, uint32_t begin_bit) {
     if (n == 0) return;
     if (end_bit == 0) end_bit = 1;
     if (end_bit > sizeof(KeyT) * 8) end_bit = sizeof(KeyT) * 8;
@@ -174,12 +174,12 @@ void pdl_sort_pairs(pdl_ctx *c, KeyT *&keys_in, KeyT *&keys_out, ValT *&vals_in,
     uint32_t *counts = c->sort_tmp.as<uint32_t>(), *offs = counts + table;
     uint64_t *d_total = c->scalars.as<uint64_t>() + 15;
     const uint32_t passes = (end_bit + 7) / 8;
-    for (uint32_t p = 0; p < passes; p++) {
+    for (uint32_t p = begin_bit / 8; p < passes; p++) {
         const uint32_t shift = p * 8;
         hipLaunchKernelGGL((k_rs_hist<KeyT>), dim3(n_tiles), dim3(RS_THREADS), 0, c->stream, keys_in, n, d_n, shift, n_tiles, counts);
         scan_and_apply(c, table, RsCountFlag{counts}, RsOffsApply{offs}, d_total);
         hipLaunchKernelGGL((k_rs_scatter<KeyT, ValT>), dim3(n_tiles), dim3(RS_THREADS), 0, c->stream, keys_in,
-                           (p == 0 && iota_values) ? (const ValT *) nullptr : vals_in, keys_out, vals_out, n, d_n, shift, n_tiles, offs);
+                           (p == begin_bit / 8 && iota_values) ? (const ValT *) nullptr : vals_in, keys_out, vals_out, n, d_n, shift, n_tiles, offs);
         PDL_HIP(hipGetLastError());
         std::swap(keys_in, keys_out);
         std::swap(vals_in, vals_out);
@@ -190,6 +190,11 @@ void pdl_sort_pairs(pdl_ctx *c, KeyT *&keys_in, KeyT *&keys_out, ValT *&vals_in,
     std::swap(vals_in, vals_out);
 }
 
-template void pdl_sort_pairs<uint32_t, uint32_t>(pdl_ctx *, uint32_t *&, uint32_t *&, uint32_t *&, uint32_t *&, uint64_t, uint32_t, bool, const uint64_t *);
-template void pdl_sort_pairs<uint64_t, uint32_t>(pdl_ctx *, uint64_t *&, uint64_t *&, uint32_t *&, uint32_t *&, uint64_t, uint32_t, bool, const uint64_t *);
-template void pdl_sort_pairs<uint32_t, unsigned long long>(pdl_ctx *, uint32_t *&, uint32_t *&, unsigned long long *&, unsigned long long *&, uint64_t, uint32_t, bool, const uint64_t *);
+void pdl_radix_offsets(pdl_ctx *c, const uint32_t *counts, uint32_t *offs, uint32_t n_tiles, uint64_t *d_total) {
+    static_assert(PDL_RADIX_TILE == RS_TILE && PDL_RADIX_BINS == RS_BINS, "the caller's kernels use the tile shape of the sort");
+    scan_and_apply(c, (size_t) RS_BINS * n_tiles, RsCountFlag{counts}, RsOffsApply{offs}, d_total);
+}
+
+template void pdl_sort_pairs<uint32_t, uint32_t>(pdl_ctx *, uint32_t *&, uint32_t *&, uint32_t *&, uint32_t *&, uint64_t, uint32_t, bool, const uint64_t *, uint32_t);
+template void pdl_sort_pairs<uint64_t, uint32_t>(pdl_ctx *, uint64_t *&, uint64_t *&, uint32_t *&, uint32_t *&, uint64_t, uint32_t, bool, const uint64_t *, uint32_t);
+template void pdl_sort_pairs<uint32_t, unsigned long long>(pdl_ctx *, uint32_t *&, uint32_t *&, unsigned long long *&, unsigned long long *&, uint64_t, uint32_t, bool, const uint64_t *, uint32_t);

@@ -70,6 +70,8 @@ struct JoinArgs {
     uint32_t *overflow_count;
     uint32_t *error_count;         // internal consistency violations (must stay 0)
     uint32_t *overflow_rows;
+    unsigned long long *defer;     // filter tiers: per workgroup, the first light sightings of the row in hand {column, 0xffffffff - group key}
+    uint32_t defer_cap;            // entries per workgroup; a row with more goes to the next tier
     // HBM tables (k_join_hbm only): per workgroup acc u64[N], first u32[N], touched u32[N], emit u32[N]
     unsigned long long *hbm_acc;
     uint32_t *hbm_u32;
@@ -135,6 +137,12 @@ __device__ __forceinline__ float finalize_cell(unsigned long long acc, uint32_t 
 // Rows whose keys do not fit are appended to an overflow list for the next tier.
 // ------------------------------------------------------------------------------------------------
 
+// loads / stores that go to L2 (agent scope): tables and lists in HBM that a workgroup writes and reads back
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 template <int HT_BITS_, int T_, bool FILTER>
 struct JoinCfg {
     static constexpr uint32_t HT = 1u << HT_BITS_;
@@ -164,7 +172,7 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
     __shared__ uint32_t s_cum[RB + 66];               // exclusive prefix of their lengths, 0xffffffff beyond the batch
     __shared__ uint32_t s_wave[17];
     __shared__ uint2 s_wstart[T_ / PDL_WAVE];          // per wave: {range holding the first lookup of its segment, that range's start}
-    __shared__ uint32_t s_ntouched, s_nemit, s_overflow, s_next, s_batch_end;
+    __shared__ uint32_t s_ntouched, s_nemit, s_overflow, s_next, s_batch_end, s_ndefer;
     __shared__ uint4 s_desc;
     __shared__ unsigned long long s_base, s_chunk_next, s_chunk_end;
 
@@ -406,11 +414,21 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
             // single-sighting columns may be dropped only if nobody involved has <= 2k k-mers
             const bool filter_on = my_kcnt > 2 * a.k && a.min_kseq > 2 * a.k;
             for (uint32_t i = tid; i < Cfg::BM_WORDS / 4; i += T) reinterpret_cast<uint4 *>(s_bm)[i] = make_uint4(0, 0, 0, 0);
-            uint32_t total = 0;
-            for (uint32_t b0 = 0; b0 < nr; b0 += RB) {       // pass 1: which columns need a slot
-                total = stage(e0, b0, min(RB, nr - b0));     // (its barriers also cover the bitmap clear)
-                walk(total, [&](const uint2 (&po)[4], const uint2 (&gm)[4], const uint32_t (&)[4], const bool (&live)[4]) {
-                    bool ins[4];
+            if (tid == 0) s_ndefer = 0;
+            unsigned long long *defer = a.defer + (size_t) blockIdx.x * a.defer_cap;
+            const uint32_t lane = tid & (PDL_WAVE - 1);
+            const unsigned long long lt_mask = (1ull << lane) - 1ull;
+            // ONE walk.  A light lookup (both counts 1) whose column's bit is still clear is the column's first sighting: it
+            // sets the bit and is put aside — {column, group} appended to this workgroup's list in HBM (coalesced, one LDS
+            // atomic per wave and iteration; the list is rewritten row after row, it lives in L2).  Every other lookup
+            // (a heavy one, or the bit is already set: a second sighting, or another column's bit under a hash collision)
+            // gets a slot and is added at once.  When the walk is over the kept columns are known, and the lookups put
+            // aside are looked up in the table: those whose column has a slot add their (1, 1, 1), the others are the
+            // single sightings that cannot be emitted.  Every lookup is counted exactly once either way.
+            for (uint32_t b0 = 0; b0 < nr; b0 += RB) {
+                const uint32_t total = stage(e0, b0, min(RB, nr - b0));     // (its barriers also cover the bitmap clear)
+                walk(total, [&](const uint2 (&po)[4], const uint2 (&gm)[4], const uint32_t (&gsv)[4], const bool (&live)[4]) {
+                    bool ins[4], later[4];
                     uint32_t old[4], bit[4];
 #pragma unroll
                     for (uint32_t u = 0; u < 4; u++) {       // four bitmap atomics in flight
@@ -419,40 +437,64 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
                         bit[u] = 1u << (h & 31);
                         old[u] = (live[u] && !ins[u]) ? atomicOr(&s_bm[h >> 5], bit[u]) : 0u;
                     }
+                    unsigned long long m[4];
+                    uint32_t n_later = 0;
 #pragma unroll
                     for (uint32_t u = 0; u < 4; u++) {
-                        if ((ins[u] || (old[u] & bit[u])) && !*(volatile uint32_t *) &s_overflow) {   // <= 1 insertion per lane after the flag
+                        later[u] = live[u] && !ins[u] && !(old[u] & bit[u]);
+                        m[u] = __ballot(later[u]);
+                        n_later += (uint32_t) __popcll(m[u]);
+                    }
+                    uint32_t at = 0;
+                    if (n_later) {                           // (wave-uniform) room in the list for this iteration's first sightings
+                        if (lane == 0) at = atomicAdd(&s_ndefer, n_later);
+                        at = (uint32_t) __builtin_amdgcn_readfirstlane((int) at);
+                        if (at + n_later > a.defer_cap) s_overflow = 1;
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; u++) {
+                        if (later[u]) {
+                            const uint32_t i = at + (uint32_t) __popcll(m[u] & lt_mask);
+                            if (i < a.defer_cap) st_agent(&defer[i], (unsigned long long) po[u].x | ((unsigned long long) (0xffffffffu - gsv[u]) << 32));
+                        } else if (live[u] && !*(volatile uint32_t *) &s_overflow) {   // <= 1 insertion per lane after the flag
                             uint32_t seen;
-                            (void) find_or_insert(po[u].x, seen);
+                            const uint32_t slot = find_or_insert(po[u].x, seen);
+                            add_to(slot, seen, po[u].y, gm[u].y, 0xffffffffu - gsv[u]);
                         }
+                        at += (uint32_t) __popcll(m[u]);
                     }
                 });
                 __syncthreads();
             }
-            if (!s_overflow) {
-                for (uint32_t b0 = 0; b0 < nr; b0 += RB) {   // pass 2: add every contribution of the kept columns
-                    if (nr > RB) total = stage(e0, b0, min(RB, nr - b0));   // single batch: still staged
-                    walk(total, [&](const uint2 (&po)[4], const uint2 (&gm)[4], const uint32_t (&gsv)[4], const bool (&live)[4]) {
-                        uint32_t slot[4];
-                        uint2 kf[4];
+            if (!s_overflow) {                               // the lookups put aside: add the ones whose column was kept
+                const uint32_t nd = s_ndefer;
+                for (uint32_t i0 = 0; i0 < nd; i0 += 4 * T) {
+                    unsigned long long e[4];
+                    uint32_t slot[4];
+                    uint2 kf[4];
 #pragma unroll
-                        for (uint32_t u = 0; u < 4; u++) {   // four first probes in flight
-                            slot[u] = (po[u].x * 2654435761u) >> (32 - HT_BITS_);
+                    for (uint32_t u = 0; u < 4; u++) {       // four loads, then four first probes in flight
+                        const uint32_t i = i0 + u * T + tid;
+                        e[u] = ld_agent(&defer[i < nd ? i : nd - 1]);
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; u++) {
+                        slot[u] = ((uint32_t) e[u] * 2654435761u) >> (32 - HT_BITS_);
+                        kf[u] = s_kf[slot[u]];
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; u++) {
+                        if (i0 + u * T + tid >= nd) continue;
+                        const uint32_t col = (uint32_t) e[u];
+                        for (;;) {
+                            if (kf[u].x == col) { add_to(slot[u], kf[u].y, 1u, 1u, (uint32_t) (e[u] >> 32)); break; }
+                            if (kf[u].x == EMPTY_KEY) break;         // column was seen once only
+                            slot[u] = (slot[u] + 1) & (HT - 1);
                             kf[u] = s_kf[slot[u]];
                         }
-#pragma unroll
-                        for (uint32_t u = 0; u < 4; u++) {
-                            if (!live[u]) continue;
-                            for (;;) {
-                                if (kf[u].x == po[u].x) { add_to(slot[u], kf[u].y, po[u].y, gm[u].y, 0xffffffffu - gsv[u]); break; }
-                                if (kf[u].x == EMPTY_KEY) break;     // column was seen once only
-                                slot[u] = (slot[u] + 1) & (HT - 1);
-                                kf[u] = s_kf[slot[u]];
-                            }
-                        }
-                    });
-                    __syncthreads();
+                    }
                 }
+                __syncthreads();
             }
         }
         const uint32_t ntouched = min(s_ntouched, TOUCH_CAP);
@@ -540,10 +582,6 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
 // tables is an L2-level atomic or an agent-scope (L1-bypassing) load/store, so the workgroup sees
 // its own updates without fences.  Tables are all-zero between rows.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t ld_agent(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // WIDE = true keeps the three sums in separate 32-bit counters (the reference's int arrays, library.cpp:421-423) instead of
 // the packed 21-bit fields: the only path for datasets with a gene of >= 2^20 k-mers, where every row is sent here.
@@ -1223,6 +1261,15 @@ static void score_join(pdl_ctx *c, const ScorePlan &pl) {
     a.work = nullptr; a.desc = c->row_desc.as<uint4>(); a.n_work = pl.wide ? 0 : n_rows; a.n_work_ptr = nullptr;
     a.work_cursor = ctr32 + 0; a.overflow_count = ctr32 + 1; a.overflow_rows = list_a;
     a.work_batch = std::max<uint32_t>(1, std::min<uint32_t>(8, n_rows / (std::max<uint32_t>(pl.grid1, 1) * 8)));
+    if (tier1 >= 9 && tier1 <= 11) {
+        // the filter tiers put a row's first sightings aside in a list per workgroup (8 bytes each; rewritten row after row, so
+        // only the part in use is ever hot): room for 4x the lookups of the average row (never more than one per gene), a
+        // row with more first sightings goes to tier 2
+        const unsigned long long avg = n_rows ? c->P / n_rows : 0;
+        a.defer_cap = (uint32_t) std::min<unsigned long long>(std::min<unsigned long long>(std::max<unsigned long long>(4 * avg, 8192), 1u << 18), (unsigned long long) N + 64);
+        c->join_defer.alloc((size_t) pl.grid1 * a.defer_cap * sizeof(unsigned long long));
+        a.defer = c->join_defer.as<unsigned long long>();
+    }
     if (tier1 == 9) hipLaunchKernelGGL((k_join_lds<9, 128, true>), dim3(pl.grid1), dim3(128), 0, st, a);
     else if (tier1 == 10) hipLaunchKernelGGL((k_join_lds<10, 256, true>), dim3(pl.grid1), dim3(256), 0, st, a);
     else if (tier1 == 11) hipLaunchKernelGGL((k_join_lds<11, 256, true>), dim3(pl.grid1), dim3(256), 0, st, a);

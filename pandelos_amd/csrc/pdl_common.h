@@ -202,6 +202,7 @@ struct pdl_ctx {
     // tuning / test switches (pdl_set_option)
     int opt_tier1 = -1;           // -1: by genome count
     bool opt_tiny_tier2 = false;
+    int opt_grid_pct = 0;         // > 0: tier-1 grid as a percentage of what fits the chip (experiments)
     bool opt_host_mirror = true;
     uint64_t opt_staging_cap = 0; // 0: estimate
 

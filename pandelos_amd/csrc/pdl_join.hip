@@ -172,7 +172,8 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
     __shared__ uint32_t s_cum[RB + 66];               // exclusive prefix of their lengths, 0xffffffff beyond the batch
     __shared__ uint32_t s_wave[17];
     __shared__ uint2 s_wstart[T_ / PDL_WAVE];          // per wave: {range holding the first lookup of its segment, that range's start}
-    __shared__ uint32_t s_ntouched, s_nemit, s_overflow, s_next, s_batch_end, s_ndefer;
+    __shared__ uint32_t s_ntouched, s_nemit, s_overflow, s_next, s_batch_end;
+    __shared__ uint32_t s_ndefer[T_ / PDL_WAVE];
     __shared__ uint4 s_desc;
     __shared__ unsigned long long s_base, s_chunk_next, s_chunk_end;
 
@@ -191,7 +192,8 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
     const uint32_t tc_min = min_numerator(threshold, (float) (int) a.min_kseq);
     const bool track_first = a.canonical == 0;
 
-    // insert column c if it has no slot yet; returns the slot (table can never be full, see TOUCH_CAP)
+    // insert column c if it has no slot yet; returns the slot (table can never be full, see TOUCH_CAP), NO_SLOT once the row has overflowed
+    constexpr uint32_t NO_SLOT = 0xffffffffu;
     auto find_or_insert = [&](uint32_t c, uint32_t &seen_first) -> uint32_t {
         uint32_t slot = (c * 2654435761u) >> (32 - HT_BITS_);
         for (;;) {
@@ -199,6 +201,10 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
             seen_first = kf.y;
             if (kf.x == c) return slot;
             if (kf.x == EMPTY_KEY) {
+                // a look at the key count on the (rare) insert path bounds the table: every thread that passes adds at most
+                // one key before it looks again, so there are never more than LIMIT + T of them — and no lookup has to poll
+                // the overflow flag (an LDS read per lookup, on a kernel whose LDS pipe is the busy one)
+                if (*(volatile uint32_t *) &s_ntouched >= LIMIT) { s_overflow = 1; return NO_SLOT; }
                 const uint32_t old = atomicCAS(&s_kf[slot].x, EMPTY_KEY, c);
                 if (old == EMPTY_KEY) {
                     const uint32_t idx = atomicAdd(&s_ntouched, 1u);
@@ -231,10 +237,8 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
                 const uint32_t i = tid * RPT + j;
                 len[j] = 0;
                 if (i < nb) {
-                    const uint32_t l = rg8[j].y & 0x3fffffu;
-                    uint32_t own = rg8[j].y >> 22;
-                    if (own == 1023u) own = a.post[rg8[j].x - 1].y;      // (rare) the k-mer occurs >= 1023 times in this gene
-                    s_gm[i] = make_uint2(rg8[j].x, own); s_gsv[i] = rg8[j].x + l; len[j] = l;
+                    s_gm[i] = rg8[j];                                    // as it is: the walk unpacks it (one LDS read per lookup instead of two)
+                    len[j] = rg8[j].y & 0x3fffffu;
                 }
                 sum += len[j];
             }
@@ -295,6 +299,15 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
     // rs+1+l (rs = range holding the chunk's first lookup, carried in scalar registers); the starts that fall
     // inside the chunk are turned into a 64-bit boundary mask with scalar ops, and a lane's range is rs +
     // popcount(boundaries at or below the lane), its offset the distance to the last such boundary.
+    // a staged range as the lookups use it: gm.y = the row's own count of the k-mer, gsv = the value that names the group
+    const bool packed = a.ranges8 != nullptr;
+    auto unpack = [&](uint2 &gm, uint32_t &gsv, uint32_t r, bool live) {
+        if (packed) {                                        // (uniform) {first posting, postings | min(own, 1023) << 22}: the group is named by its end
+            gsv = gm.x + (gm.y & 0x3fffffu);
+            gm.y >>= 22;
+            if (__builtin_expect(gm.y == 1023u && live, 0)) gm.y = a.post[gm.x - 1].y;       // (rare) the k-mer occurs >= 1023 times in this gene; (a dead lane holds no range)
+        } else gsv = s_gsv[r];
+    };
     auto walk = [&](uint32_t total, auto &&fn4) {
         constexpr uint32_t NW = T / PDL_WAVE;
         const uint32_t lane = tid & (PDL_WAVE - 1), wave = tid / PDL_WAVE;
@@ -332,8 +345,8 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
                         const uint32_t off = below ? lane - (63u - (uint32_t) __clzll((long long) below)) : f - start_u;
                         live[u] = f < total;
                         gm[u] = s_gm[r];
-                        gsv[u] = s_gsv[r];
                         adr[u] = gm[u].x + off;
+                        unpack(gm[u], gsv[u], r, live[u]);
                     }
                 }
                 const uint32_t ce = (uint32_t) __popcll(__ballot(vw <= f_hi));             // range holding the next iteration's first lookup
@@ -356,8 +369,8 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
                     const uint32_t off = below ? lane - (63u - (uint32_t) __clzll((long long) below)) : f - cum_rs;
                     live[u] = f < total;
                     gm[u] = s_gm[r];
-                    gsv[u] = s_gsv[r];
                     adr[u] = gm[u].x + off;
+                    unpack(gm[u], gsv[u], r, live[u]);
                     // keep the invariant "rs holds the first lookup of the next chunk": a range may start exactly there
                     const uint32_t nextb = w < PDL_WAVE ? __builtin_amdgcn_readlane(v, w) : s_cum[rs + 1 + PDL_WAVE];
                     if (nextb == f0 + PDL_WAVE) { rs += w + 1; cum_rs = nextb; }
@@ -402,10 +415,10 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
                 walk(total, [&](const uint2 (&po)[4], const uint2 (&gm)[4], const uint32_t (&gsv)[4], const bool (&live)[4]) {
 #pragma unroll
                     for (uint32_t u = 0; u < 4; u++) {
-                        if (!live[u] || *(volatile uint32_t *) &s_overflow) continue;   // <= 1 insertion per lane after the flag
+                        if (!live[u]) continue;
                         uint32_t seen;
                         const uint32_t slot = find_or_insert(po[u].x, seen);
-                        add_to(slot, seen, po[u].y, gm[u].y, 0xffffffffu - gsv[u]);
+                        if (slot != NO_SLOT) add_to(slot, seen, po[u].y, gm[u].y, 0xffffffffu - gsv[u]);
                     }
                 });
                 __syncthreads();
@@ -414,13 +427,16 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
             // single-sighting columns may be dropped only if nobody involved has <= 2k k-mers
             const bool filter_on = my_kcnt > 2 * a.k && a.min_kseq > 2 * a.k;
             for (uint32_t i = tid; i < Cfg::BM_WORDS / 4; i += T) reinterpret_cast<uint4 *>(s_bm)[i] = make_uint4(0, 0, 0, 0);
-            if (tid == 0) s_ndefer = 0;
+            constexpr uint32_t NWV = T / PDL_WAVE;
+            const uint32_t wcap = a.defer_cap / NWV;               // every wave files its own part of the list: the count stays in a scalar register
             unsigned long long *defer = a.defer + (size_t) blockIdx.x * a.defer_cap;
+            unsigned long long *wdefer = defer + (size_t) (tid / PDL_WAVE) * wcap;
+            uint32_t nd_w = 0;
             const uint32_t lane = tid & (PDL_WAVE - 1);
             const unsigned long long lt_mask = (1ull << lane) - 1ull;
             // ONE walk.  A light lookup (both counts 1) whose column's bit is still clear is the column's first sighting: it
-            // sets the bit and is put aside — {column, group} appended to this workgroup's list in HBM (coalesced, one LDS
-            // atomic per wave and iteration; the list is rewritten row after row, it lives in L2).  Every other lookup
+            // sets the bit and is put aside — {column, group} appended to its wave's part of this workgroup's list in HBM
+            // (coalesced; the count is a scalar register; the list is rewritten row after row, it lives in L2).  Every other lookup
             // (a heavy one, or the bit is already set: a second sighting, or another column's bit under a hash collision)
             // gets a slot and is added at once.  When the walk is over the kept columns are known, and the lookups put
             // aside are looked up in the table: those whose column has a slot add their (1, 1, 1), the others are the
@@ -445,37 +461,41 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
                         m[u] = __ballot(later[u]);
                         n_later += (uint32_t) __popcll(m[u]);
                     }
-                    uint32_t at = 0;
-                    if (n_later) {                           // (wave-uniform) room in the list for this iteration's first sightings
-                        if (lane == 0) at = atomicAdd(&s_ndefer, n_later);
-                        at = (uint32_t) __builtin_amdgcn_readfirstlane((int) at);
-                        if (at + n_later > a.defer_cap) s_overflow = 1;
-                    }
+                    uint32_t at = nd_w;
+                    nd_w += n_later;
+                    if (nd_w > wcap) s_overflow = 1;             // (wave-uniform) no room for this iteration's first sightings: next tier
 #pragma unroll
                     for (uint32_t u = 0; u < 4; u++) {
                         if (later[u]) {
                             const uint32_t i = at + (uint32_t) __popcll(m[u] & lt_mask);
-                            if (i < a.defer_cap) st_agent(&defer[i], (unsigned long long) po[u].x | ((unsigned long long) (0xffffffffu - gsv[u]) << 32));
-                        } else if (live[u] && !*(volatile uint32_t *) &s_overflow) {   // <= 1 insertion per lane after the flag
+                            if (i < wcap) st_agent(&wdefer[i], (unsigned long long) po[u].x | ((unsigned long long) (0xffffffffu - gsv[u]) << 32));
+                        } else if (live[u]) {
                             uint32_t seen;
                             const uint32_t slot = find_or_insert(po[u].x, seen);
-                            add_to(slot, seen, po[u].y, gm[u].y, 0xffffffffu - gsv[u]);
+                            if (slot != NO_SLOT) add_to(slot, seen, po[u].y, gm[u].y, 0xffffffffu - gsv[u]);
                         }
                         at += (uint32_t) __popcll(m[u]);
                     }
                 });
+                if (b0 + RB >= nr && lane == 0) s_ndefer[tid / PDL_WAVE] = nd_w;
                 __syncthreads();
             }
+            static_assert(NWV <= 4, "the pass below takes one entry per wave and step");
             if (!s_overflow) {                               // the lookups put aside: add the ones whose column was kept
-                const uint32_t nd = s_ndefer;
-                for (uint32_t i0 = 0; i0 < nd; i0 += 4 * T) {
+                uint32_t ndw[NWV], nd_max = 0;
+#pragma unroll
+                for (uint32_t w = 0; w < NWV; w++) { ndw[w] = s_ndefer[w]; nd_max = max(nd_max, ndw[w]); }
+                for (uint32_t i0 = 0; i0 < nd_max; i0 += (4 / NWV ? 4 / NWV : 1) * T) {
+                    // four entries per thread and step: with four waves, one from every wave's part
                     unsigned long long e[4];
                     uint32_t slot[4];
                     uint2 kf[4];
+                    bool have[4];
 #pragma unroll
                     for (uint32_t u = 0; u < 4; u++) {       // four loads, then four first probes in flight
-                        const uint32_t i = i0 + u * T + tid;
-                        e[u] = ld_agent(&defer[i < nd ? i : nd - 1]);
+                        const uint32_t w = u % NWV, i = i0 + (u / NWV) * T + tid;
+                        have[u] = i < ndw[w];
+                        e[u] = ld_agent(&defer[(size_t) w * wcap + (have[u] ? i : 0u)]);
                     }
 #pragma unroll
                     for (uint32_t u = 0; u < 4; u++) {
@@ -484,7 +504,7 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
                     }
 #pragma unroll
                     for (uint32_t u = 0; u < 4; u++) {
-                        if (i0 + u * T + tid >= nd) continue;
+                        if (!have[u]) continue;
                         const uint32_t col = (uint32_t) e[u];
                         for (;;) {
                             if (kf[u].x == col) { add_to(slot[u], kf[u].y, 1u, 1u, (uint32_t) (e[u] >> 32)); break; }
@@ -1169,6 +1189,7 @@ static ScorePlan score_plan(pdl_ctx *c) {
     pl.occ_slot = tier1 >= 20 ? tier1 - 20 + 3 : (tier1 ? tier1 - 9 : 0);
     if (tier1 && c->occ_tier1[pl.occ_slot] == 0) c->occ_tier1[pl.occ_slot] = occupancy(fn1, t1_threads);
     pl.grid1 = tier1 ? std::min<uint32_t>(n_rows, (uint32_t) cus * c->occ_tier1[pl.occ_slot]) : 0;
+    if (c->opt_grid_pct > 0 && pl.grid1) pl.grid1 = std::max<uint32_t>(1, (uint32_t) ((uint64_t) pl.grid1 * (uint32_t) c->opt_grid_pct / 100));     // (experiments: fewer rows in flight)
     pl.grid2 = std::min<uint32_t>(n_rows, (uint32_t) cus * (pl.tiny_tier2 ? 4 : 1));
     pl.grid3 = (uint32_t) std::min<int>(cus, 64);
     const size_t hbm_bytes = (size_t) pl.grid3 * N * ((pl.wide ? 2 : 1) * sizeof(uint64_t) + 3 * sizeof(uint32_t));

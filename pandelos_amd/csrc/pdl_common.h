@@ -177,6 +177,7 @@ struct pdl_ctx {
     uint64_t Z = 0;
     DevBuf join_ctr;      // u32 [8] cursors/counters of the join
     DevBuf overflow_rows; // u32 [n_task_rows]
+    DevBuf gene_info;             // uint4 [N] {k-mers, genome, task position, shard-local genome}: one load per candidate column in finalize
     DevBuf join_defer;            // filter tiers of the join: per workgroup, the first sightings put aside
     DevBuf glb_table;     // HBM tables of the overflow pass
     bool glb_clean = false;   // all-zero (k_join_hbm leaves them that way)

@@ -43,6 +43,8 @@ struct JoinArgs {
     const uint32_t *seq_off;
     const uint32_t *kseq_len;
     const uint32_t *genome_of;
+    const uint4 *gene_info;        // per gene {k-mers, genome, task position (0xffffffff: not this context's row), shard-local index of its genome}:
+                                   // what finalize wants to know about a column, in ONE dependent load instead of four
     const uint32_t *task_rows;     // gene id of task position p
     const uint32_t *task_lg;       // shard-local genome of task position p
     const uint32_t *work;          // task positions to process (k_join_hbm: the overflow list)
@@ -407,7 +409,8 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
             if (tid == 0) { a.row_base[p] = 0; a.row_cnt[p] = 0; s_next = next_reg; s_desc = next_desc; }
             continue;
         }
-        const uint32_t my_kcnt = a.kseq_len[r];
+        const uint4 row_info = a.gene_info[r];
+        const uint32_t my_kcnt = row_info.x;
         // ---- lookups (library.cpp:461-479) -----------------------------------------------------------
         if constexpr (!FILTER) {
             for (uint32_t b0 = 0; b0 < nr; b0 += RB) {
@@ -539,9 +542,9 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
             s_base = nx;
         }
         const uint32_t pc_min = min_numerator(threshold, (float) (int) my_kcnt);
-        const uint32_t my_genome = a.genome_of[r];
+        const uint32_t my_genome = row_info.y;
         float *ms_row = a.MS + (size_t) p * a.G;
-        float *cm_row = a.CM + (size_t) a.task_lg[p] * a.N;
+        float *cm_row = a.CM + (size_t) row_info.w * a.N;
         __syncthreads();
         const unsigned long long base = s_base;
         const bool fits = base + ntouched <= a.st_cap;
@@ -559,7 +562,8 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
             // drop a candidate without a division or a fetch of K_c.
             if ((uint32_t) ((acc >> 21) & FIELD_MASK) < pc_min && (uint32_t) (acc >> 42) < tc_min) continue;
             float perc, tr;
-            const float score = finalize_cell(acc, my_kcnt, a.kseq_len[c], threshold, perc, tr);
+            const uint4 ci = a.gene_info[c];
+            const float score = finalize_cell(acc, my_kcnt, ci.x, threshold, perc, tr);
             if (score > 0.0f) {
                 const uint32_t i = atomicAdd(&s_nemit, 1u);
                 if (fits) {
@@ -567,19 +571,19 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
                     a.st_score[o] = score; a.st_perc[o] = perc; a.st_tr[o] = tr;
                     a.st_col[o] = c; a.st_first[o] = 0xffffffffu - kf.y;
                     // scores are positive floats: their bit patterns order like the values
-                    const uint32_t gc = a.genome_of[c];
+                    const uint32_t gc = ci.y;
                     atomicMax(reinterpret_cast<uint32_t *>(ms_row + gc), __float_as_uint(score));
                     atomicMax(reinterpret_cast<uint32_t *>(cm_row + c), __float_as_uint(score));
                     if (a.mirror) {
                         // the same sums seen from gene c: cell (c, r) with perc and tr_perc swapped (both quotients
                         // use the same integers the row program of c would have summed); K-order places it in c's row.
                         // Multi-GPU: when c is another GPU's row the staged cell travels there (k_outbox_*).
-                        const uint32_t pc = a.taskpos_of[c];
+                        const uint32_t pc = ci.z;
                         a.st_src[o] = r;
                         if (pc != 0xffffffffu) {
                             atomicAdd(&a.mirror_cnt[pc], 1u);
                             atomicMax(reinterpret_cast<uint32_t *>(a.MS + (size_t) pc * a.G + my_genome), __float_as_uint(score));
-                            atomicMax(reinterpret_cast<uint32_t *>(a.CM + (size_t) a.local_genome[gc] * a.N + r), __float_as_uint(score));
+                            atomicMax(reinterpret_cast<uint32_t *>(a.CM + (size_t) ci.w * a.N + r), __float_as_uint(score));
                         }
                     }
                 }
@@ -1030,9 +1034,17 @@ __global__ __launch_bounds__(256) void k_mirror_refs_inbox(const uint32_t *__res
 }
 
 // work-item descriptors of the LDS join, in processing order (currently task order)
+// ... and what the join wants to know about a gene when it meets it as a column, gathered into one 16-byte record
 __global__ __launch_bounds__(256) void k_row_desc(const uint32_t *__restrict__ task_rows, const uint32_t *__restrict__ seq_off,
-                                                  uint32_t n_rows, uint4 *__restrict__ desc) {
+                                                  uint32_t n_rows, uint4 *__restrict__ desc,
+                                                  const uint32_t *__restrict__ kseq_len, const uint32_t *__restrict__ genome_of,
+                                                  const uint32_t *__restrict__ taskpos_of, const uint32_t *__restrict__ local_genome,
+                                                  uint32_t n_genes, uint4 *__restrict__ gene_info) {
     const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    if (p < n_genes) {
+        const uint32_t g = genome_of[p];
+        gene_info[p] = make_uint4(kseq_len[p], g, taskpos_of[p], local_genome[g]);
+    }
     if (p >= n_rows) return;
     const uint32_t r = task_rows[p];
     const uint32_t e0 = seq_off[r];
@@ -1215,8 +1227,10 @@ static void score_alloc_rows(pdl_ctx *c, const ScorePlan &pl) {
     c->row_desc2.alloc((size_t) n_rows * sizeof(uint4));
     c->overflow_rows.alloc((size_t) n_rows * 4 * 2);     // list A (tier 1 -> 2) and list B (tier 2 -> 3)
     if (pl.mirror) c->mirror_cnt.alloc((size_t) n_rows * 4 * 3 + 16);    // counts | offsets | cursors
-    hipLaunchKernelGGL(k_row_desc, dim3((n_rows + 255) / 256), dim3(256), 0, c->stream, c->task_rows.as<uint32_t>(), c->seq_off.as<uint32_t>(),
-                       n_rows, c->row_desc.as<uint4>());
+    c->gene_info.alloc((size_t) N * sizeof(uint4));
+    hipLaunchKernelGGL(k_row_desc, dim3((std::max(n_rows, N) + 255) / 256), dim3(256), 0, c->stream, c->task_rows.as<uint32_t>(), c->seq_off.as<uint32_t>(),
+                       n_rows, c->row_desc.as<uint4>(), c->kseq_len.as<uint32_t>(), c->d_gen, c->taskpos_of.as<uint32_t>(), c->local_genome.as<uint32_t>(),
+                       N, c->gene_info.as<uint4>());
 }
 
 // staging for `cap` cells of this context's rows + `extra` cells received from other GPUs (slots cap .. cap + extra)
@@ -1234,7 +1248,7 @@ static void score_alloc_cells(pdl_ctx *c, const ScorePlan &pl, unsigned long lon
 static JoinArgs join_args(pdl_ctx *c, const ScorePlan &pl) {
     JoinArgs a{};
     a.post = pdl_postings(c); a.ranges = c->ranges.as<uint4>(); a.ranges8 = c->ranges8; a.seq_off = c->seq_off.as<uint32_t>();
-    a.kseq_len = c->kseq_len.as<uint32_t>(); a.genome_of = c->d_gen;
+    a.kseq_len = c->kseq_len.as<uint32_t>(); a.genome_of = c->d_gen; a.gene_info = c->gene_info.as<uint4>();
     a.task_rows = c->task_rows.as<uint32_t>(); a.task_lg = c->task_lg.as<uint32_t>();
     a.N = c->N; a.G = c->G; a.k = c->rp.k;
     a.min_kseq = (uint32_t) std::max<uint64_t>(c->min_kseq, 1); a.canonical = (c->flags & PDL_FLAG_CANONICAL_ORDER) ? 1u : 0u;

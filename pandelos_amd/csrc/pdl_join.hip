@@ -72,6 +72,9 @@ struct JoinArgs {
     uint32_t *overflow_count;
     uint32_t *error_count;         // internal consistency violations (must stay 0)
     uint32_t *overflow_rows;
+#ifdef PDL_JOIN_PHASES
+    unsigned long long *phase;     // diagnostic build (-DPDL_JOIN_PHASES): time the first thread of every workgroup spends in the phases of a row (100-MHz ticks, summed)
+#endif
     unsigned long long *defer;     // filter tiers: per workgroup, the first light sightings of the row in hand {column, 0xffffffff - group key}
     uint32_t defer_cap;            // entries per workgroup; a row with more goes to the next tier
     // HBM tables (k_join_hbm only): per workgroup acc u64[N], first u32[N], touched u32[N], emit u32[N]
@@ -194,6 +197,14 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
     const uint32_t tc_min = min_numerator(threshold, (float) (int) a.min_kseq);
     const bool track_first = a.canonical == 0;
 
+#ifdef PDL_JOIN_PHASES
+    unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_prev = wall_clock64();
+#define PH_MARK(i) do { if (tid == 0) { const unsigned long long t_now = wall_clock64(); ph[i] += t_now - t_prev; t_prev = t_now; } } while (0)
+#define PH_WAIT() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#else
+#define PH_MARK(i) do { } while (0)
+#define PH_WAIT() do { } while (0)
+#endif
     // insert column c if it has no slot yet; returns the slot (table can never be full, see TOUCH_CAP), NO_SLOT once the row has overflowed
     constexpr uint32_t NO_SLOT = 0xffffffffu;
     auto find_or_insert = [&](uint32_t c, uint32_t &seen_first) -> uint32_t {
@@ -380,8 +391,10 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
                 }
             }
             }
+            PH_WAIT(); PH_MARK(5);
 #pragma unroll
             for (uint32_t u = 0; u < 4; u++) po[u] = a.post[live[u] ? adr[u] : 0u];     // dead lanes (last chunk) read posting 0: no exec juggling
+            PH_WAIT(); PH_MARK(6);
             fn4(po, gm, gsv, live);
         }
     };
@@ -391,6 +404,7 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
         const uint32_t wi = s_next;
         const uint4 d = s_desc;
         __syncthreads();
+        PH_MARK(0);
         if (wi >= n_work) break;                         // uniform: every wave leaves here
         // the next row's ticket and descriptor are fetched now and parked in registers of lane 0 until the
         // end of this row, so the row after this one starts without a dependent global load
@@ -446,6 +460,7 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
             // single sightings that cannot be emitted.  Every lookup is counted exactly once either way.
             for (uint32_t b0 = 0; b0 < nr; b0 += RB) {
                 const uint32_t total = stage(e0, b0, min(RB, nr - b0));     // (its barriers also cover the bitmap clear)
+                PH_MARK(1);
                 walk(total, [&](const uint2 (&po)[4], const uint2 (&gm)[4], const uint32_t (&gsv)[4], const bool (&live)[4]) {
                     bool ins[4], later[4];
                     uint32_t old[4], bit[4];
@@ -456,6 +471,7 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
                         bit[u] = 1u << (h & 31);
                         old[u] = (live[u] && !ins[u]) ? atomicOr(&s_bm[h >> 5], bit[u]) : 0u;
                     }
+                    PH_WAIT(); PH_MARK(7);
                     unsigned long long m[4];
                     uint32_t n_later = 0;
 #pragma unroll
@@ -479,9 +495,14 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
                         }
                         at += (uint32_t) __popcll(m[u]);
                     }
+#ifdef PDL_JOIN_PHASES
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); PH_MARK(8);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PH_MARK(9);
+#endif
                 });
                 if (b0 + RB >= nr && lane == 0) s_ndefer[tid / PDL_WAVE] = nd_w;
                 __syncthreads();
+                PH_MARK(2);
             }
             static_assert(NWV <= 4, "the pass below takes one entry per wave and step");
             if (!s_overflow) {                               // the lookups put aside: add the ones whose column was kept
@@ -520,6 +541,7 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
                 __syncthreads();
             }
         }
+        PH_MARK(3);
         const uint32_t ntouched = min(s_ntouched, TOUCH_CAP);
         if (s_overflow) {
             // too many keys for this table: hand the row to the next tier, wipe the table
@@ -590,6 +612,7 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
             }
         }
         __syncthreads();
+        PH_MARK(4);
         if (tid == 0) {
             const uint32_t nemit = s_nemit;
             a.row_base[p] = fits ? (uint32_t) base : 0u;
@@ -599,6 +622,11 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
             s_ntouched = 0; s_nemit = 0; s_next = next_reg; s_desc = next_desc;
         }
     }
+#ifdef PDL_JOIN_PHASES
+    if (tid == 0 && a.phase) { for (int i = 0; i < 10; i++) atomicAdd(&a.phase[i], ph[i]); }
+#endif
+#undef PH_MARK
+#undef PH_WAIT
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1305,11 +1333,29 @@ static void score_join(pdl_ctx *c, const ScorePlan &pl) {
         c->join_defer.alloc((size_t) pl.grid1 * a.defer_cap * sizeof(unsigned long long));
         a.defer = c->join_defer.as<unsigned long long>();
     }
+#ifdef PDL_JOIN_PHASES
+    static unsigned long long *d_phase = nullptr;
+    if (!d_phase) PDL_HIP(hipMalloc((void **) &d_phase, 10 * sizeof(unsigned long long)));
+    PDL_HIP(hipMemsetAsync(d_phase, 0, 10 * sizeof(unsigned long long), st));
+    a.phase = d_phase;
+#endif
     if (tier1 == 9) hipLaunchKernelGGL((k_join_lds<9, 128, true>), dim3(pl.grid1), dim3(128), 0, st, a);
     else if (tier1 == 10) hipLaunchKernelGGL((k_join_lds<10, 256, true>), dim3(pl.grid1), dim3(256), 0, st, a);
     else if (tier1 == 11) hipLaunchKernelGGL((k_join_lds<11, 256, true>), dim3(pl.grid1), dim3(256), 0, st, a);
     else if (tier1 == 20) hipLaunchKernelGGL((k_join_lds<10, 256, false>), dim3(pl.grid1), dim3(256), 0, st, a);
     else if (tier1 == 21) hipLaunchKernelGGL((k_join_lds<11, 256, false>), dim3(pl.grid1), dim3(256), 0, st, a);
+#ifdef PDL_JOIN_PHASES
+    {   // (the timers wait for every access they bracket, which serialises the walk: read the shares, not the sum)
+        unsigned long long h[10];
+        PDL_HIP(hipMemcpyAsync(h, d_phase, sizeof(h), hipMemcpyDeviceToHost, st));
+        PDL_HIP(hipStreamSynchronize(st));
+        const double per = 10.0 / 1000.0 / std::max<uint32_t>(pl.grid1, 1);       // ticks of 10 ns -> us per workgroup
+        fprintf(stderr, "join phases per workgroup (us): dispense %.1f  stage %.1f  [walk: map %.1f  postings %.1f  bitmap %.1f  table %.1f  aside stores %.1f]  barrier %.1f  aside pass %.1f  finalize %.1f  | rows/wg %.1f\n",
+                h[0] * per, h[1] * per, h[5] * per, h[6] * per, h[7] * per, h[8] * per, h[9] * per, h[2] * per, h[3] * per, h[4] * per,
+                (double) n_rows / std::max<uint32_t>(pl.grid1, 1));
+        a.phase = nullptr;
+    }
+#endif
     // tier 2 over list A (or over everything when tier 1 is off)
     if (tier1) {
         hipLaunchKernelGGL(k_row_desc_list, dim3((n_rows + 255) / 256), dim3(256), 0, st, list_a, ctr32 + 1, c->task_rows.as<uint32_t>(),

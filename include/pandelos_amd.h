@@ -176,7 +176,9 @@ PDL_API int pdl_get_timings(pdl_ctx *, pdl_timings *out);
  * "join_tiny_tier2" 0|1 (512-slot second tier, so that small test sets reach the HBM-table kernel), "host_mirror" 0|1
  * (pdl_compute_scores slices ONE pinned copy of the whole result (1, default) or copies each genome's block from the
  * device (0); results above 1 GiB always take the second way), "staging_cap" n (cells of staging the first scoring
- * attempt may use, 0 = estimate; a pass that overflows it is repeated once with the exact size). */
+ * attempt may use, 0 = estimate; a pass that overflows it is repeated once with the exact size), "join_grid_pct" n (first
+ * tier of the join launched with n % of the workgroups the chip holds, 0 = all: an experiment knob — how the join scales
+ * with rows in flight). */
 PDL_API int pdl_set_option(pdl_ctx *, const char *name, int64_t value);
 
 /* ---- multi-GPU: one context per GPU, the caller moves bytes between them (RCCL over xGMI) -----------------------

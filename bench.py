@@ -120,17 +120,18 @@ class Runner:
         self.nat = PangeneNative.open(stream=self.stream)
         for name, value in self.options:
             self.nat.set_option(name, value)
+        self.step_args = (self.k, self.t_res.data_ptr(), self.t_off.data_ptr(), self.t_gen.data_ptr(), gs.genes, len(gs.residues))
         self.dp = None
         if self.distributed:
             from pandelos_amd.distributed import DistributedPangenes
             self.dp = DistributedPangenes(self.nat, self.dev, self.on_dev)
 
     def step(self):
-        gs = self.gs
         if self.dp is None:
-            self.nat.preprocess_device(self.k, self.t_res.data_ptr(), self.t_off.data_ptr(), self.t_gen.data_ptr(), gs.genes, len(gs.residues))
+            self.nat.preprocess_device(*self.step_args)
             self.nat.score_all()
         else:
+            gs = self.gs
             self.dp.preprocess(self.k, self.t_res, self.t_off, self.t_gen, gs.genes, len(gs.residues))
             self.dp.score_all()
 
@@ -144,20 +145,25 @@ class Runner:
         from pandelos_amd import distributed as D
         for _ in range(warmup):
             self.step()
+        self.nat.set_option("stage_timers", 0)      # the timed steps carry the events of the totals and of the join only
+        self.step()
         self.sync()
         t0 = time.perf_counter()
         join_ms, pre_ms, score_ms, xd, xc = [], [], [], [], []
         for _ in range(steps):
             self.step()
-            tm = self.nat.timings()
-            join_ms.append(tm["join_ms"] + tm["join_overflow_ms"])
-            pre_ms.append(tm["preprocess_total_ms"])
-            score_ms.append(tm["score_total_ms"])
+            ts = self.nat.timings_struct()           # (HIP-event times of this step's launches; three fields, no dictionary: the loop is timed)
+            join_ms.append(ts.join_ms + ts.join_overflow_ms)
+            pre_ms.append(ts.preprocess_total_ms)
+            score_ms.append(ts.score_total_ms)
             if self.dp is not None:
                 xd.append(self.dp.exchange_s["dictionary"] * 1e3); xc.append(self.dp.exchange_s["cells"] * 1e3)
         self.sync()
         elapsed = D.all_reduce_max(time.perf_counter() - t0, device=coll_dev)
         sec_per_step = elapsed / max(steps, 1)
+        self.nat.set_option("stage_timers", 1)      # one more step, untimed, for the per-stage breakdown (stage_ms)
+        self.step()
+        self.sync()
         gs, cost, tm = self.gs, self.nat.cost, self.nat.timings()
         mean = lambda v: sum(v) / len(v) if v else 0.0
         # algorithmic bytes of this rank's join launch (SURVEY.md §8d join terms; lookups as the reference counts them)

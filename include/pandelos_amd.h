@@ -178,7 +178,9 @@ PDL_API int pdl_get_timings(pdl_ctx *, pdl_timings *out);
  * device (0); results above 1 GiB always take the second way), "staging_cap" n (cells of staging the first scoring
  * attempt may use, 0 = estimate; a pass that overflows it is repeated once with the exact size), "join_grid_pct" n (first
  * tier of the join launched with n % of the workgroups the chip holds, 0 = all: an experiment knob — how the join scales
- * with rows in flight). */
+ * with rows in flight), "stage_timers" 0|1 (default 1: HIP events around every stage fill the stage
+ * fields of pdl_timings; 0: only the totals and the join's launch time are taken — each event pair is two marker packets
+ * between dispatches, a few microseconds of idle stream on a two-millisecond step). */
 PDL_API int pdl_set_option(pdl_ctx *, const char *name, int64_t value);
 
 /* ---- multi-GPU: one context per GPU, the caller moves bytes between them (RCCL over xGMI) -----------------------

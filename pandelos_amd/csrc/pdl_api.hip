@@ -45,7 +45,8 @@ pdl_ctx *pdl_create(const pdl_config *cfg) {
         c->flags = cfg ? cfg->flags : 0;
         if (cfg && cfg->stream) { c->stream = (hipStream_t) cfg->stream; c->own_stream = false; }
         else { PDL_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
-        if (hipHostMalloc((void **) &c->pin, 1 << 20, hipHostMallocDefault) == hipSuccess) c->pin_bytes = 1 << 20;
+        // (coherent = fine-grained: what a kernel stores there is visible to the host while the kernel still runs — PinRead's flag)
+        if (hipHostMalloc((void **) &c->pin, 1 << 20, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) { c->pin_bytes = 1 << 20; memset(c->pin + c->pin_bytes - PDL_PIN_FLAG_BYTES, 0, PDL_PIN_FLAG_BYTES); }
         else { c->pin = nullptr; (void) hipGetLastError(); }
         return c;
     } catch (const pdl_error &e) {
@@ -65,6 +66,8 @@ void pdl_destroy(pdl_ctx *c) {
     if (c->mirror) (void) hipHostFree(c->mirror);
     if (c->edge_mirror) (void) hipHostFree(c->edge_mirror);
     if (c->task_pin) (void) hipHostFree(c->task_pin);
+    if (c->ev_tasks) (void) hipEventDestroy(c->ev_tasks);
+    if (c->copy_stream) (void) hipStreamDestroy(c->copy_stream);
     if (c->gen_pin) (void) hipHostFree(c->gen_pin);
     if (c->ev_gen) (void) hipEventDestroy(c->ev_gen);
     delete c;
@@ -500,6 +503,7 @@ int pdl_set_option(pdl_ctx *c, const char *name, int64_t value) {
         c->opt_tier1 = (int) value;
     } else if (n == "join_tiny_tier2") c->opt_tiny_tier2 = value != 0;
     else if (n == "join_grid_pct") c->opt_grid_pct = (int) value;
+    else if (n == "stage_timers") c->opt_stage_timers = value != 0;
     else if (n == "host_mirror") c->opt_host_mirror = value != 0;
     else if (n == "staging_cap") c->opt_staging_cap = value > 0 ? (uint64_t) value : 0;
     else { c->err = "unknown option " + n; return PDL_ERR_ARGUMENT; }

@@ -2,6 +2,9 @@
 // gfx950 only: wave = 64 lanes, 160 KiB LDS per CU, no other target is considered.
 #pragma once
 
+#include <atomic>
+#include <chrono>
+
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -165,6 +168,7 @@ struct pdl_ctx {
     // task layout on the device: one allocation, one upload from a pinned staging buffer (pdl_prepare_tasks)
     DevBuf task_blob;
     uint32_t *task_pin = nullptr; size_t task_pin_words = 0;
+    hipStream_t copy_stream = nullptr; hipEvent_t ev_tasks = nullptr;     // uploads of the task layout, beside the build's stream
     DevView task_rows;    // u32 [n_task_rows] gene id of each task position
     DevView task_lg;      // u32 [n_task_rows] shard-local genome index
     DevBuf row_desc;      // uint4 [n_task_rows] {task position, gene, first range, ranges} in processing order
@@ -203,6 +207,7 @@ struct pdl_ctx {
     // tuning / test switches (pdl_set_option)
     int opt_tier1 = -1;           // -1: by genome count
     bool opt_tiny_tier2 = false;
+    bool opt_stage_timers = true; // per-stage HIP events (pdl_timings' stage fields); the totals and the join's are always taken
     int opt_grid_pct = 0;         // > 0: tier-1 grid as a percentage of what fits the chip (experiments)
     bool opt_host_mirror = true;
     uint64_t opt_staging_cap = 0; // 0: estimate
@@ -229,6 +234,7 @@ struct pdl_ctx {
     EventPair ev[16];
     uint8_t *pin = nullptr;       // pinned host scratch for the small device->host reads (true async DMA, no staging copy)
     size_t pin_bytes = 0;
+    uint32_t pin_epoch = 0;       // last value a k_pin_read raised the flag at the tail of `pin` to
     // host mirror of the whole scoring result (pinned): filled by ONE set of device->host copies at the first
     // pdl_compute_scores after a scoring pass, so the per-genome calls are host memcpys (results up to PDL_MIRROR_LIMIT)
     uint8_t *mirror = nullptr;
@@ -237,25 +243,81 @@ struct pdl_ctx {
 };
 
 // Small device->host reads through the pinned scratch: queue with add(), one sync(), then read the returned pointers.
+// Small device -> host reads (counters, control blocks) WITHOUT a DMA copy and without hipStreamSynchronize: on this
+// platform a copy of a few hundred bytes is ~30 us of copy-engine latency and the wake-up from a stream wait another
+// 20-30 — and a step of the 64-genome set has three such reads.  Instead one tiny kernel, stream-ordered behind the work
+// it reads, stores the words straight into pinned host memory (PCIe posted writes), fences at system scope and raises an
+// epoch flag in the same buffer; the host spins on the flag (a few us).  A read that is large, oddly sized or does not
+// fit the pinned buffer, and a wait that outlasts the spin budget (the stream has long kernels ahead), take the old road.
+struct PinReadArgs {
+    const uint32_t *src[8];
+    uint32_t dst_word[8], words[8];
+    uint32_t n;
+    uint32_t *pin;             // pinned host buffer as the device sees it
+    uint32_t flag_word, epoch;
+};
+static __global__ __launch_bounds__(256) void k_pin_read(PinReadArgs a) {
+    for (uint32_t s = 0; s < a.n; s++)
+        for (uint32_t i = threadIdx.x; i < a.words[s]; i += 256) a.pin[a.dst_word[s] + i] = a.src[s][i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) { *(volatile uint32_t *) (a.pin + a.flag_word) = a.epoch; __threadfence_system(); }
+}
+constexpr size_t PDL_PIN_FLAG_BYTES = 64;                    // the tail of the pinned buffer holds the flag
 struct PinRead {
     pdl_ctx *c;
     size_t used = 0;
+    PinReadArgs k{};
+    bool by_copy = false;                                    // at least one read went through hipMemcpyAsync
     std::vector<std::pair<void *, std::pair<const void *, size_t>>> spill;   // reads that did not fit: done pageable
     explicit PinRead(pdl_ctx *ctx) : c(ctx) {}
     template <class T> const T *add(const void *d_src, size_t count) {
         const size_t bytes = count * sizeof(T);
         const size_t at = (used + 15) & ~(size_t) 15;
-        if (c->pin && at + bytes <= c->pin_bytes) {
+        const size_t room = c->pin_bytes > PDL_PIN_FLAG_BYTES ? c->pin_bytes - PDL_PIN_FLAG_BYTES : 0;
+        if (c->pin && at + bytes <= room) {
             used = at + bytes;
-            PDL_HIP(hipMemcpyAsync(c->pin + at, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+            if (k.n < 8 && bytes % 4 == 0 && bytes <= (64u << 10) && (reinterpret_cast<uintptr_t>(d_src) & 3) == 0) {
+                k.src[k.n] = static_cast<const uint32_t *>(d_src); k.dst_word[k.n] = (uint32_t) (at / 4); k.words[k.n] = (uint32_t) (bytes / 4);
+                k.n++;
+            } else {
+                by_copy = true;
+                PDL_HIP(hipMemcpyAsync(c->pin + at, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+            }
             return reinterpret_cast<const T *>(c->pin + at);
         }
         void *h = malloc(bytes ? bytes : 1);
         spill.push_back({h, {d_src, bytes}});
+        by_copy = true;
         PDL_HIP(hipMemcpyAsync(h, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
         return reinterpret_cast<const T *>(h);
     }
-    void sync() { PDL_HIP(hipStreamSynchronize(c->stream)); }
+    bool issued = false;
+    void issue() {                                           // queue the read now; the host may do other work before wait()
+        if (issued) return;
+        issued = true;
+        if (!k.n) return;
+        k.pin = reinterpret_cast<uint32_t *>(c->pin);
+        k.flag_word = (uint32_t) ((c->pin_bytes - PDL_PIN_FLAG_BYTES) / 4);
+        k.epoch = ++c->pin_epoch;
+        hipLaunchKernelGGL(k_pin_read, dim3(1), dim3(256), 0, c->stream, k);
+        PDL_HIP(hipGetLastError());
+    }
+    void sync() {
+        issue();
+        if (k.n) {
+            if (!by_copy) {
+                volatile uint32_t *flag = reinterpret_cast<volatile uint32_t *>(c->pin) + k.flag_word;
+                const auto t0 = std::chrono::steady_clock::now();
+                for (uint32_t spins = 0; *flag != k.epoch; spins++) {
+                    if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+                    __builtin_ia32_pause();
+                }
+                if (*flag == k.epoch) { std::atomic_thread_fence(std::memory_order_acquire); return; }
+            }
+        }
+        PDL_HIP(hipStreamSynchronize(c->stream));
+    }
     ~PinRead() { for (auto &e : spill) free(e.first); }
 };
 
@@ -277,12 +339,17 @@ inline uint2 *pdl_postings(const pdl_ctx *c) { return c->post_ext ? c->post_ext 
 enum { EV_HIST, EV_RANK, EV_SORT1, EV_DICT, EV_SORT2, EV_RANGES, EV_JOIN, EV_JOIN_OVF, EV_ORDER, EV_PRE_TOTAL, EV_SCORE_TOTAL,
        EV_DIST_BEGIN, EV_DIST_FINISH, EV_DIST_SCORE_FINISH, EV_COUNT };
 
+// An event record is a marker packet between two dispatches (a few us of idle stream each); the per-stage pairs can be
+// switched off ("stage_timers" 0) when only the totals and the join's launch time are wanted (bench.py's timed loop).
+inline bool ev_is_stage(int i) { return i == EV_HIST || i == EV_RANK || i == EV_SORT1 || i == EV_DICT || i == EV_SORT2 || i == EV_RANGES || i == EV_ORDER; }
 inline void ev_begin(pdl_ctx *c, int i) {
+    c->ev[i].used = false;
+    if (!c->opt_stage_timers && ev_is_stage(i)) return;
     if (!c->ev[i].a) { PDL_HIP(hipEventCreate(&c->ev[i].a)); PDL_HIP(hipEventCreate(&c->ev[i].b)); }
     PDL_HIP(hipEventRecord(c->ev[i].a, c->stream));
-    c->ev[i].used = false;
 }
 inline void ev_end(pdl_ctx *c, int i) {
+    if (!c->opt_stage_timers && ev_is_stage(i)) return;
     PDL_HIP(hipEventRecord(c->ev[i].b, c->stream));
     c->ev[i].used = true;
 }

@@ -1116,13 +1116,14 @@ static void stage_alphabet_and_lengths(pdl_ctx *c, int kvalue, bool only_complex
         hipLaunchKernelGGL(k_hist, dim3(blocks), dim3(HIST_THREADS), 0, st, c->d_res, c->R,
                            reinterpret_cast<unsigned long long *>(d_scal + PDL_CTL_HIST));
     }
-    if (c->layout_deferred) pdl_finish_layout(c);        // host work (genes by genome) while the histogram runs
     uint64_t counters[256];
     uint64_t M = 0, bad = 0;
     {
         PinRead rd(c);
-        const uint64_t *pc = rd.add<uint64_t>(d_scal, PDL_CTL_GCOST);          // scalars + histogram in one copy
+        const uint64_t *pc = rd.add<uint64_t>(d_scal, PDL_CTL_GCOST);          // scalars + histogram in one read
         ev_end(c, EV_HIST);
+        rd.issue();
+        if (c->layout_deferred) pdl_finish_layout(c);    // host work (genes by genome) while the histogram runs and its counters travel
         rd.sync();
         memcpy(counters, pc + PDL_CTL_HIST, sizeof(counters));
         M = pc[5]; bad = pc[3];

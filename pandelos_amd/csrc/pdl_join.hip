@@ -1137,11 +1137,12 @@ void pdl_prepare_tasks(pdl_ctx *c) {
     // one pinned staging buffer, filled in place: task_rows[n_rows] | task_lg[n_rows] | taskpos_of[N] | local_genome[G]
     // -> ONE upload (separate copies from pageable vectors were five staged transfers with the device idle in between)
     const size_t words = 2 * (size_t) n_rows + N + G;
-    if (c->task_pin_words < words) {
+    const size_t words_all = words + S + 1;                  // ... | task_row_off[S + 1] (goes to its own buffer)
+    if (c->task_pin_words < words_all) {
         if (c->task_pin) (void) hipHostFree(c->task_pin);
         c->task_pin = nullptr; c->task_pin_words = 0;
-        PDL_HIP(hipHostMalloc((void **) &c->task_pin, (words + words / 4 + 16) * sizeof(uint32_t), hipHostMallocDefault));
-        c->task_pin_words = words + words / 4 + 16;
+        PDL_HIP(hipHostMalloc((void **) &c->task_pin, (words_all + words_all / 4 + 16) * sizeof(uint32_t), hipHostMallocDefault));
+        c->task_pin_words = words_all + words_all / 4 + 16;
     }
     uint32_t *h_rows = c->task_pin, *h_lg = h_rows + n_rows, *h_pos = h_lg + n_rows, *h_loc = h_pos + N;
     for (uint32_t i = 0; i < N; i++) h_pos[i] = 0xffffffffu;
@@ -1156,17 +1157,26 @@ void pdl_prepare_tasks(pdl_ctx *c) {
     c->h_task_row_off[S] = n_rows;
     c->n_task_rows = n_rows;
     c->tasks_ready = true;
+    // The uploads travel on a stream of their own: a copy queued between two kernels of the build costs ~10 us of idle
+    // stream on either side (the blit's barrier packets) — here the build's kernels go on undisturbed and the main stream
+    // waits for the event, which has long fired when the first kernel that reads the task layout comes up.
+    if (!c->copy_stream) {
+        PDL_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        PDL_HIP(hipEventCreateWithFlags(&c->ev_tasks, hipEventDisableTiming));
+    }
+    memcpy(c->task_pin + words, c->h_task_row_off.data(), (size_t) (S + 1) * 4);
     c->task_blob.alloc(words * sizeof(uint32_t) + 16);
-    PDL_HIP(hipMemcpyAsync(c->task_blob.p, c->task_pin, words * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    if (n_rows) c->task_off.alloc((size_t) (S + 1) * 8 + 64);      // task offsets | gathered cell offsets + 8 counters + cell total
+    PDL_HIP(hipMemcpyAsync(c->task_blob.p, c->task_pin, words * sizeof(uint32_t), hipMemcpyHostToDevice, c->copy_stream));
+    if (n_rows) PDL_HIP(hipMemcpyAsync(c->task_off.p, c->task_pin + words, (size_t) (S + 1) * 4, hipMemcpyHostToDevice, c->copy_stream));
+    PDL_HIP(hipEventRecord(c->ev_tasks, c->copy_stream));
+    PDL_HIP(hipStreamWaitEvent(st, c->ev_tasks, 0));
     uint32_t *d = c->task_blob.as<uint32_t>();
     c->task_rows.p = d; c->task_lg.p = d + n_rows; c->taskpos_of.p = d + 2 * (size_t) n_rows; c->local_genome.p = d + 2 * (size_t) n_rows + N;
     if (c->dist) {            // genome -> rank, for the cell exchange
         c->owner_of_genome.alloc((size_t) G * 4);
         PDL_HIP(hipMemcpyAsync(c->owner_of_genome.p, c->h_owner.data(), (size_t) G * 4, hipMemcpyHostToDevice, st));
     }
-    if (n_rows == 0) return;
-    c->task_off.alloc((size_t) (S + 1) * 8 + 64);      // task offsets | gathered cell offsets + 8 counters + cell total
-    PDL_HIP(hipMemcpyAsync(c->task_off.p, c->h_task_row_off.data(), (size_t) (S + 1) * 4, hipMemcpyHostToDevice, st));
 }
 
 __global__ void k_iota_u32(uint32_t *dst, uint32_t n) { uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) dst[i] = i; }

@@ -229,6 +229,10 @@ class PangeneNative:
         return tab, lm.value
 
     def timings(self) -> dict:
+        return self.timings_struct().as_dict()
+
+    def timings_struct(self):
+        """pdl_timings as the ctypes structure (no dictionary is built: for callers inside a timed loop)."""
         t = _lib.PdlTimings()
         self._check(self._lib.pdl_get_timings(self._ctx, C.byref(t)))
-        return t.as_dict()
+        return t

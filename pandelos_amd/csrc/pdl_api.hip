@@ -67,6 +67,7 @@ void pdl_destroy(pdl_ctx *c) {
     if (c->edge_mirror) (void) hipHostFree(c->edge_mirror);
     if (c->task_pin) (void) hipHostFree(c->task_pin);
     if (c->ev_tasks) (void) hipEventDestroy(c->ev_tasks);
+    if (c->ev_entry) (void) hipEventDestroy(c->ev_entry);
     if (c->copy_stream) (void) hipStreamDestroy(c->copy_stream);
     if (c->gen_pin) (void) hipHostFree(c->gen_pin);
     if (c->ev_gen) (void) hipEventDestroy(c->ev_gen);
@@ -204,10 +205,19 @@ int pdl_preprocess_device(pdl_ctx *c, const uint8_t *d_residues, const uint64_t 
         }
         if (!c->ev_gen) PDL_HIP(hipEventCreateWithFlags(&c->ev_gen, hipEventDisableTiming));
         uint64_t *ends = reinterpret_cast<uint64_t *>(c->gen_pin + (((size_t) n + 1) & ~(size_t) 1));
-        PDL_HIP(hipMemcpyAsync(ends, d_offsets, 8, hipMemcpyDeviceToHost, c->stream));
-        PDL_HIP(hipMemcpyAsync(ends + 1, d_offsets + n, 8, hipMemcpyDeviceToHost, c->stream));
-        PDL_HIP(hipMemcpyAsync(c->gen_pin, d_genome_of, (size_t) n * 4, hipMemcpyDeviceToHost, c->stream));
-        PDL_HIP(hipEventRecord(c->ev_gen, c->stream));
+        // (on the side stream, behind whatever the caller's stream holds so far: the build's first kernels do not queue up
+        //  behind three copies)
+        if (!c->copy_stream) {
+            PDL_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+            PDL_HIP(hipEventCreateWithFlags(&c->ev_tasks, hipEventDisableTiming));
+        }
+        if (!c->ev_entry) PDL_HIP(hipEventCreateWithFlags(&c->ev_entry, hipEventDisableTiming));
+        PDL_HIP(hipEventRecord(c->ev_entry, c->stream));
+        PDL_HIP(hipStreamWaitEvent(c->copy_stream, c->ev_entry, 0));
+        PDL_HIP(hipMemcpyAsync(ends, d_offsets, 8, hipMemcpyDeviceToHost, c->copy_stream));
+        PDL_HIP(hipMemcpyAsync(ends + 1, d_offsets + n, 8, hipMemcpyDeviceToHost, c->copy_stream));
+        PDL_HIP(hipMemcpyAsync(c->gen_pin, d_genome_of, (size_t) n * 4, hipMemcpyDeviceToHost, c->copy_stream));
+        PDL_HIP(hipEventRecord(c->ev_gen, c->copy_stream));
         c->layout_deferred = true;
     }
     PDL_GUARD_END(c)

@@ -168,7 +168,7 @@ struct pdl_ctx {
     // task layout on the device: one allocation, one upload from a pinned staging buffer (pdl_prepare_tasks)
     DevBuf task_blob;
     uint32_t *task_pin = nullptr; size_t task_pin_words = 0;
-    hipStream_t copy_stream = nullptr; hipEvent_t ev_tasks = nullptr;     // uploads of the task layout, beside the build's stream
+    hipStream_t copy_stream = nullptr; hipEvent_t ev_tasks = nullptr, ev_entry = nullptr;     // uploads of the task layout, beside the build's stream
     DevView task_rows;    // u32 [n_task_rows] gene id of each task position
     DevView task_lg;      // u32 [n_task_rows] shard-local genome index
     DevBuf row_desc;      // uint4 [n_task_rows] {task position, gene, first range, ranges} in processing order

@@ -25,6 +25,10 @@
 
 #define RABIN_MODULO 18446744073709551557ULL   /* 2^64 - 59, library.cpp:19 */
 
+
+__global__ __launch_bounds__(256) void k_zero_u64(uint64_t *p, size_t n) {
+    for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t) gridDim.x * 256) p[i] = 0;
+}
 // ------------------------------------------------------------------------------------------------
 // K-hist: 256-bin histogram of the residue bytes (library.cpp:216-228).  16-byte coalesced loads,
 // per-workgroup LDS histogram (8 copies, padded so that equal values of different copies fall in different
@@ -1100,7 +1104,7 @@ static void stage_alphabet_and_lengths(pdl_ctx *c, int kvalue, bool only_complex
     const size_t ctl_words = PDL_CTL_GCOST + 2 * (size_t) (c->layout_deferred ? c->N : c->G);
     c->scalars.alloc(ctl_words * sizeof(uint64_t));
     uint64_t *d_scal = c->scalars.as<uint64_t>();
-    PDL_HIP(hipMemsetAsync(d_scal, 0, ctl_words * sizeof(uint64_t), st));
+    hipLaunchKernelGGL(k_zero_u64, dim3((uint32_t) std::min<size_t>((ctl_words + 255) / 256, 1024)), dim3(256), 0, st, d_scal, ctl_words);     // (a kernel: a fill is a blit with ~10 us of barrier packets around it)
 
     ev_begin(c, EV_HIST);
     // K-len (independent of the histogram, reads the offsets only); its apply step also clears cost[], its total also lands in kmer_off[N]
@@ -1122,8 +1126,6 @@ static void stage_alphabet_and_lengths(pdl_ctx *c, int kvalue, bool only_complex
         PinRead rd(c);
         const uint64_t *pc = rd.add<uint64_t>(d_scal, PDL_CTL_GCOST);          // scalars + histogram in one read
         ev_end(c, EV_HIST);
-        rd.issue();
-        if (c->layout_deferred) pdl_finish_layout(c);    // host work (genes by genome) while the histogram runs and its counters travel
         rd.sync();
         memcpy(counters, pc + PDL_CTL_HIST, sizeof(counters));
         M = pc[5]; bad = pc[3];
@@ -1407,6 +1409,7 @@ static void dictionary_pipeline(pdl_ctx *c, bool only_complexity) {
     uint32_t *vals_in = c->vals_a.as<uint32_t>(), *vals_out = c->vals_b.as<uint32_t>();
     stage_sort_and_dedup<KeyT>(c, keys_in, keys_out, vals_in, vals_out, M);
     ev_end(c, EV_DICT);
+    if (c->layout_deferred) pdl_finish_layout(c);   // device input: the genome layout is host work too, and nothing before this point needed it
     if (!only_complexity) pdl_prepare_tasks(c);     // host work + small uploads while the device sorts
     // U (records) and the range count stay on the device until the end of the build: everything below is sized and
     // launched for the bound M and reads the counts there — no host round trip in the middle of the pipeline

@@ -153,7 +153,7 @@ class Runner:
         for _ in range(steps):
             self.step()
             ts = self.nat.timings_struct()           # (HIP-event times of this step's launches; three fields, no dictionary: the loop is timed)
-            join_ms.append(ts.join_ms + ts.join_overflow_ms)
+            join_ms.append(ts.join_ms)               # (all three tiers)
             pre_ms.append(ts.preprocess_total_ms)
             score_ms.append(ts.score_total_ms)
             if self.dp is not None:

@@ -89,7 +89,7 @@ typedef struct {
  * stream (milliseconds), and the counters the roofline needs. */
 typedef struct {
     float hist_ms, rank_ms, sort_rank_ms, dict_ms, sort_seq_ms, ranges_ms;  /* preprocess */
-    float join_ms, join_overflow_ms, order_ms;                             /* scoring */
+    float join_ms, join_overflow_ms, order_ms;                             /* scoring: the join's three tiers; of which the HBM-table tier; K-order */
     float preprocess_total_ms, score_total_ms;
     uint64_t emitted_cells;        /* Z over the genomes scored by this context */
     uint64_t scored_rows;          /* rows (genes) scored by this context */

@@ -257,11 +257,23 @@ struct PinReadArgs {
     uint32_t flag_word, epoch;
 };
 static __global__ __launch_bounds__(256) void k_pin_read(PinReadArgs a) {
+    __shared__ uint32_t s_sum;
+    if (threadIdx.x == 0) s_sum = 0;
+    __syncthreads();
+    uint32_t sum = 0;
     for (uint32_t s = 0; s < a.n; s++)
-        for (uint32_t i = threadIdx.x; i < a.words[s]; i += 256) a.pin[a.dst_word[s] + i] = a.src[s][i];
+        for (uint32_t i = threadIdx.x; i < a.words[s]; i += 256) { const uint32_t v = a.src[s][i]; a.pin[a.dst_word[s] + i] = v; sum += v * (2u * i + 1u); }
+    atomicAdd(&s_sum, sum);
     __threadfence_system();
     __syncthreads();
-    if (threadIdx.x == 0) { *(volatile uint32_t *) (a.pin + a.flag_word) = a.epoch; __threadfence_system(); }
+    // The flag says "all of it has been sent", the checksum beside it lets the host see that all of it has ARRIVED: the
+    // words travel from several waves over several paths, and the flag may overtake the last of them.
+    if (threadIdx.x == 0) {
+        *(volatile uint32_t *) (a.pin + a.flag_word + 1) = s_sum;
+        __threadfence_system();
+        *(volatile uint32_t *) (a.pin + a.flag_word) = a.epoch;
+        __threadfence_system();
+    }
 }
 constexpr size_t PDL_PIN_FLAG_BYTES = 64;                    // the tail of the pinned buffer holds the flag
 struct PinRead {
@@ -308,12 +320,22 @@ struct PinRead {
         if (k.n) {
             if (!by_copy) {
                 volatile uint32_t *flag = reinterpret_cast<volatile uint32_t *>(c->pin) + k.flag_word;
+                const volatile uint32_t *words = reinterpret_cast<const volatile uint32_t *>(c->pin);
+                auto arrived = [&]() -> bool {               // flag up and every word in place (position-weighted sum, as the kernel made it)
+                    if (flag[0] != k.epoch) return false;
+                    std::atomic_thread_fence(std::memory_order_acquire);
+                    uint32_t sum = 0;
+                    for (uint32_t sgm = 0; sgm < k.n; sgm++)
+                        for (uint32_t i = 0; i < k.words[sgm]; i++) sum += words[k.dst_word[sgm] + i] * (2u * i + 1u);
+                    return sum == flag[1];
+                };
                 const auto t0 = std::chrono::steady_clock::now();
-                for (uint32_t spins = 0; *flag != k.epoch; spins++) {
-                    if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+                bool ok = false;
+                for (uint32_t spins = 0; !(ok = arrived()); spins++) {
+                    if ((spins & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
                     __builtin_ia32_pause();
                 }
-                if (*flag == k.epoch) { std::atomic_thread_fence(std::memory_order_acquire); return; }
+                if (ok) { std::atomic_thread_fence(std::memory_order_acquire); return; }
             }
         }
         PDL_HIP(hipStreamSynchronize(c->stream));
@@ -341,7 +363,7 @@ enum { EV_HIST, EV_RANK, EV_SORT1, EV_DICT, EV_SORT2, EV_RANGES, EV_JOIN, EV_JOI
 
 // An event record is a marker packet between two dispatches (a few us of idle stream each); the per-stage pairs can be
 // switched off ("stage_timers" 0) when only the totals and the join's launch time are wanted (bench.py's timed loop).
-inline bool ev_is_stage(int i) { return i == EV_HIST || i == EV_RANK || i == EV_SORT1 || i == EV_DICT || i == EV_SORT2 || i == EV_RANGES || i == EV_ORDER; }
+inline bool ev_is_stage(int i) { return i == EV_HIST || i == EV_RANK || i == EV_SORT1 || i == EV_DICT || i == EV_SORT2 || i == EV_RANGES || i == EV_ORDER || i == EV_JOIN_OVF; }
 inline void ev_begin(pdl_ctx *c, int i) {
     c->ev[i].used = false;
     if (!c->opt_stage_timers && ev_is_stage(i)) return;

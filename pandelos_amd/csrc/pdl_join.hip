@@ -178,12 +178,12 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
     __shared__ uint32_t s_wave[17];
     __shared__ uint2 s_wstart[T_ / PDL_WAVE];          // per wave: {range holding the first lookup of its segment, that range's start}
     __shared__ uint32_t s_ntouched, s_nemit, s_overflow, s_next, s_batch_end;
-    __shared__ uint32_t s_ndefer[T_ / PDL_WAVE];
     __shared__ uint4 s_desc;
     __shared__ unsigned long long s_base, s_chunk_next, s_chunk_end;
 
     const uint32_t tid = threadIdx.x;
     const uint32_t n_work = a.n_work_ptr ? *a.n_work_ptr : a.n_work;
+    if (n_work == 0) return;                             // (uniform) a tier nobody handed a row to: leave before the table is cleared
     for (uint32_t i = tid; i < HT; i += T) { s_kf[i] = make_uint2(EMPTY_KEY, 0u); s_acc[i] = 0; }
     for (uint32_t i = RB + tid; i < RB + 66; i += T) s_cum[i] = 0xffffffffu;
     if (tid == 0) {
@@ -500,26 +500,26 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PH_MARK(9);
 #endif
                 });
-                if (b0 + RB >= nr && lane == 0) s_ndefer[tid / PDL_WAVE] = nd_w;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the wave's (write-through) stores to its list are in L2 before it reads them back;
+                                                              // (not __threadfence(): an agent-scope release writes the L2 back — 9x the join's time)
                 __syncthreads();
                 PH_MARK(2);
             }
-            static_assert(NWV <= 4, "the pass below takes one entry per wave and step");
-            if (!s_overflow) {                               // the lookups put aside: add the ones whose column was kept
-                uint32_t ndw[NWV], nd_max = 0;
-#pragma unroll
-                for (uint32_t w = 0; w < NWV; w++) { ndw[w] = s_ndefer[w]; nd_max = max(nd_max, ndw[w]); }
-                for (uint32_t i0 = 0; i0 < nd_max; i0 += (4 / NWV ? 4 / NWV : 1) * T) {
-                    // four entries per thread and step: with four waves, one from every wave's part
+            if (!s_overflow) {
+                // The lookups put aside: add the ones whose column was kept.  Every wave goes through the part of the list
+                // it wrote itself — nothing here depends on seeing another wave's global stores (an earlier version read all
+                // four parts from every wave and, rarely, found the previous row's entries there: barrier and fence
+                // notwithstanding); the barrier above is for the table, which all waves fill.
+                for (uint32_t i0 = 0; i0 < nd_w; i0 += 4 * PDL_WAVE) {
                     unsigned long long e[4];
                     uint32_t slot[4];
                     uint2 kf[4];
                     bool have[4];
 #pragma unroll
                     for (uint32_t u = 0; u < 4; u++) {       // four loads, then four first probes in flight
-                        const uint32_t w = u % NWV, i = i0 + (u / NWV) * T + tid;
-                        have[u] = i < ndw[w];
-                        e[u] = ld_agent(&defer[(size_t) w * wcap + (have[u] ? i : 0u)]);
+                        const uint32_t i = i0 + u * PDL_WAVE + lane;
+                        have[u] = i < nd_w;
+                        e[u] = ld_agent(&wdefer[have[u] ? i : 0u]);
                     }
 #pragma unroll
                     for (uint32_t u = 0; u < 4; u++) {
@@ -538,8 +538,8 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
                         }
                     }
                 }
-                __syncthreads();
             }
+            __syncthreads();
         }
         PH_MARK(3);
         const uint32_t ntouched = min(s_ntouched, TOUCH_CAP);
@@ -1378,8 +1378,7 @@ static void score_join(pdl_ctx *c, const ScorePlan &pl) {
     if (pl.tiny_tier2) hipLaunchKernelGGL((k_join_lds<9, 64, false>), dim3(pl.grid2), dim3(64), 0, st, a);
     else hipLaunchKernelGGL((k_join_lds<13, 1024, false>), dim3(pl.grid2), dim3(1024), 0, st, a);
     PDL_HIP(hipGetLastError());
-    ev_end(c, EV_JOIN);
-    // tier 3 over list B
+    // tier 3 over list B (inside the join's event pair; its own pair is one of the optional stage timers)
     a.hbm_acc = c->glb_table.as<unsigned long long>();
     a.hbm_u32 = reinterpret_cast<uint32_t *>(a.hbm_acc + (size_t) pl.grid3 * N * (pl.wide ? 2 : 1));
     a.work = list_b; a.n_work = 0; a.n_work_ptr = ctr32 + 3; a.work_cursor = ctr32 + 7; a.work_batch = 1;
@@ -1389,6 +1388,7 @@ static void score_join(pdl_ctx *c, const ScorePlan &pl) {
     else hipLaunchKernelGGL(k_join_hbm<false>, dim3(pl.grid3), dim3(HBM_THREADS), 0, st, a);
     PDL_HIP(hipGetLastError());
     ev_end(c, EV_JOIN_OVF);
+    ev_end(c, EV_JOIN);
     c->tm.join_launches += 3;
 }
 

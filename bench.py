@@ -308,7 +308,7 @@ def main():
                    "dictionary_records": int(cost.dictionary_records), "lookups": int(m["p_total"]),
                    "lookups_walked": int(m["walked"]), "emitted_cells": int(m["z_total"]),
                    "cells_per_row": m["z_total"] / max(gs.genes, 1), "sharding": sharding},
-        "timed_region": "inputs and outputs resident in HBM (host_path = SURVEY §8d host-to-host wall time)",
+        "timed_region": "inputs and outputs resident in HBM (host_path = SURVEY §8d host-to-host wall time); timed steps carry the HIP events of the two totals and of the join only, stage_ms comes from one more step outside the timed region",
         "lookups_per_s": m["p_total"] / m["sec_per_step"],
         "stage_ms": m["stage_ms"],
         "roofline": {"bound": "hbm", "kernel": "k_join_lds (+k_join_hbm)", "achieved": achieved, "peak": HBM_PEAK_GBPS,

@@ -794,6 +794,7 @@ struct OrderArgs {
     int32_t *c_row, *c_col;
     uint32_t n_rows;
     uint32_t canonical;
+    uint32_t pack_ok;                   // fewer than 2^22 genes: (chunk, first group, column) fits one 64-bit key
     uint32_t *wide_rows;                // set by k_order_rows_wave when it leaves a row to k_order_rows
 };
 
@@ -801,6 +802,13 @@ __device__ __forceinline__ unsigned long long order_key_hi(uint32_t col, uint32_
     if (canonical) return 0ull;
     const uint32_t chunk = col == 0 ? 0u : (col - 1) >> 11;
     return ((unsigned long long) chunk << 32) | first;
+}
+
+// the whole key in 64 bits when the gene ids allow it: chunk (11 bits) | first group (32) | column inside the chunk (12, 0..2048)
+__device__ __forceinline__ unsigned long long order_key_packed(uint32_t col, uint32_t first, uint32_t canonical) {
+    if (canonical) return col;
+    const uint32_t chunk = col == 0 ? 0u : (col - 1) >> 11;
+    return ((unsigned long long) chunk << 44) | ((unsigned long long) first << 12) | (col - (chunk << 11));
 }
 
 // cell i of row p: its own staged cells first, then the mirrored ones (a mirrored cell is the staged cell of
@@ -933,6 +941,25 @@ __global__ __launch_bounds__(256) void k_order_rows_wave(OrderArgs a) {
             hi_lo[s] = (uint32_t) hi; hi_hi[s] = (uint32_t) (hi >> 32);
         }
     }
+    if (a.pack_ok) {                                     // (uniform) one 64-bit compare per pair instead of a three-word one
+        unsigned long long key[ORDER_CPL];
+#pragma unroll
+        for (uint32_t s = 0; s < ORDER_CPL; s++) {
+            const uint32_t i = s * PDL_WAVE + lane;
+            key[s] = (s < nslots && i < cnt) ? order_key_packed(col[s], a.canonical ? 0u : hi_lo[s], a.canonical) : ~0ull;
+        }
+#pragma unroll
+        for (uint32_t sj = 0; sj < ORDER_CPL; sj++) {
+            if (sj >= nslots) break;
+            const uint32_t nj = min((uint32_t) PDL_WAVE, cnt - sj * PDL_WAVE);
+            for (uint32_t j = 0; j < nj; j++) {
+                const unsigned long long kj = ((unsigned long long) (uint32_t) __shfl((int) (uint32_t) (key[sj] >> 32), (int) j, PDL_WAVE) << 32) |
+                                              (uint32_t) __shfl((int) (uint32_t) key[sj], (int) j, PDL_WAVE);
+#pragma unroll
+                for (uint32_t s = 0; s < ORDER_CPL; s++) rank[s] += kj < key[s] ? 1u : 0u;
+            }
+        }
+    } else
 #pragma unroll
     for (uint32_t sj = 0; sj < ORDER_CPL; sj++) {
         if (sj >= nslots) break;
@@ -1422,7 +1449,7 @@ static unsigned long long score_order(pdl_ctx *c, const ScorePlan &pl, uint32_t 
     o.st_col = c->st_col.as<uint32_t>(); o.st_first = c->st_first.as<uint32_t>();
     o.c_score = c->c_score.as<float>(); o.c_perc = c->c_perc.as<float>(); o.c_tr = c->c_tr.as<float>();
     o.c_row = c->c_row.as<int32_t>(); o.c_col = c->c_col.as<int32_t>();
-    o.n_rows = n_rows; o.canonical = (c->flags & PDL_FLAG_CANONICAL_ORDER) ? 1u : 0u;
+    o.n_rows = n_rows; o.canonical = (c->flags & PDL_FLAG_CANONICAL_ORDER) ? 1u : 0u; o.pack_ok = c->N < (1u << 22) ? 1u : 0u;
     o.wide_rows = ctr32 + 9;                 // (counter block, zero since the clearing launch)
     hipLaunchKernelGGL(k_order_rows_wave, dim3((n_rows + 3) / 4), dim3(256), 0, st, o);
     hipLaunchKernelGGL(k_order_rows, dim3(std::min<uint32_t>(n_rows, (uint32_t) c->cus * 8)), dim3(ORDER_THREADS), 0, st, o);   // rows of more than 256 cells, if any

@@ -7,7 +7,7 @@
 //                            and per-(row, genome) / per-column maxima.  Tier 1 = small table behind a
 //                            "seen twice" bitmap filter (several rows per CU), tier 2 = 8192-slot table
 //   K-join-hbm  k_join_hbm   tier 3: same row program with direct-addressed tables in HBM
-//   K-order     k_mirror_refs, k_order_rows   every row's cells in the reference's emission order
+//   K-order     k_mirror_cells, k_order_rows  every row's cells in the reference's emission order
 //                            (first-touch order, library.cpp:456-482,493 — SURVEY.md §8a row 9a)
 //
 // Row program (all tiers).  A row gene r owns a list of posting ranges, one per record of r that sits in a
@@ -784,12 +784,14 @@ constexpr int ORDER_TILE = 2048;
 constexpr uint32_t ORDER_CPL = 4;                              // cells per lane in the wave-per-row kernel
 constexpr uint32_t ORDER_WAVE_CELLS = ORDER_CPL * PDL_WAVE;    // rows up to this many cells are ranked inside one wave
 
+struct MCell { uint32_t col, first; float score, perc, tr; uint32_t pad; };       // a mirrored cell as its row reads it (24 bytes)
 struct OrderArgs {
     const uint32_t *row_base, *row_cnt, *fin_off, *task_rows;
     const float *st_score, *st_perc, *st_tr;
     const uint32_t *st_col, *st_first;
-    // mirror mode: row p also owns mirror_cnt[p] cells that other rows staged; mirror_ref lists their staging slots
-    const uint32_t *st_src, *mirror_cnt, *mirror_off, *mirror_ref;
+    // mirror mode: row p also owns mirror_cnt[p] cells that other rows staged; mcell holds them from mirror_off[p] on
+    const uint32_t *st_src, *mirror_cnt, *mirror_off;
+    const MCell *mcell;
     float *c_score, *c_perc, *c_tr;
     int32_t *c_row, *c_col;
     uint32_t n_rows;
@@ -811,12 +813,22 @@ __device__ __forceinline__ unsigned long long order_key_packed(uint32_t col, uin
     return ((unsigned long long) chunk << 44) | ((unsigned long long) first << 12) | (col - (chunk << 11));
 }
 
-// cell i of row p: its own staged cells first, then the mirrored ones (a mirrored cell is the staged cell of
-// another row read with row/column and perc/tr_perc swapped)
+// cell i of row p: its own staged cells first (the staging arrays, at row_base[p] + i), then the mirrored ones — the
+// staged cells of other rows as this row reads them (row/column and perc/tr_perc swapped), which k_mirror_cells has
+// COPIED into this row's stretch of `mcell`: K-order reads every cell of a row from consecutive addresses (it used to
+// follow a reference to the other row's staging slot: five dependent 4-byte gathers per mirrored cell).
 struct OrderCell { uint32_t slot; bool mirrored; };
 __device__ __forceinline__ OrderCell order_cell(const OrderArgs &a, uint32_t p, uint32_t own, uint32_t i) {
     if (i < own) return OrderCell{a.row_base[p] + i, false};
-    return OrderCell{a.mirror_ref[a.mirror_off[p] + (i - own)], true};
+    return OrderCell{a.mirror_off[p] + (i - own), true};
+}
+__device__ __forceinline__ uint2 cell_key(const OrderArgs &a, const OrderCell &oc) {          // {column, first group}
+    if (oc.mirrored) { const MCell &m = a.mcell[oc.slot]; return make_uint2(m.col, m.first); }
+    return make_uint2(a.st_col[oc.slot], a.st_first[oc.slot]);
+}
+__device__ __forceinline__ void cell_values(const OrderArgs &a, const OrderCell &oc, float &score, float &perc, float &tr) {
+    if (oc.mirrored) { const MCell &m = a.mcell[oc.slot]; score = m.score; perc = m.perc; tr = m.tr; }
+    else { score = a.st_score[oc.slot]; perc = a.st_perc[oc.slot]; tr = a.st_tr[oc.slot]; }
 }
 
 __global__ __launch_bounds__(ORDER_THREADS) void k_order_rows(OrderArgs a) {
@@ -839,9 +851,10 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_order_rows(OrderArgs a) {
         for (uint32_t j = threadIdx.x; j < n2; j += ORDER_THREADS) {
             if (j < cnt) {
                 const OrderCell oc = order_cell(a, p, own, j);
-                const uint32_t cj = oc.mirrored ? a.st_src[oc.slot] : a.st_col[oc.slot];
+                const uint2 kj = cell_key(a, oc);
+                const uint32_t cj = kj.x;
                 s_col[j] = cj;
-                s_hi[j] = order_key_hi(cj, a.st_first[oc.slot], a.canonical);
+                s_hi[j] = order_key_hi(cj, kj.y, a.canonical);
             } else {
                 s_col[j] = 0xffffffffu; s_hi[j] = ~0ull;         // padding sorts last
             }
@@ -867,9 +880,9 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_order_rows(OrderArgs a) {
         for (uint32_t q = threadIdx.x; q < cnt; q += ORDER_THREADS) {
             const OrderCell me = order_cell(a, p, own, s_idx[q]);
             const uint32_t o = out0 + q;
-            a.c_score[o] = a.st_score[me.slot];
-            a.c_perc[o] = me.mirrored ? a.st_tr[me.slot] : a.st_perc[me.slot];
-            a.c_tr[o] = me.mirrored ? a.st_perc[me.slot] : a.st_tr[me.slot];
+            float v_score, v_perc, v_tr;
+            cell_values(a, me, v_score, v_perc, v_tr);
+            a.c_score[o] = v_score; a.c_perc[o] = v_perc; a.c_tr[o] = v_tr;
             a.c_row[o] = (int32_t) row;
             a.c_col[o] = (int32_t) s_col[q];
         }
@@ -883,8 +896,9 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_order_rows(OrderArgs a) {
         OrderCell me{0, false};
         if (live) {
             me = order_cell(a, p, own, i);
-            col = me.mirrored ? a.st_src[me.slot] : a.st_col[me.slot];
-            hi = order_key_hi(col, a.st_first[me.slot], a.canonical);
+            const uint2 km = cell_key(a, me);
+            col = km.x;
+            hi = order_key_hi(col, km.y, a.canonical);
         }
         uint32_t rank = 0;
         for (uint32_t j0 = 0; j0 < cnt; j0 += ORDER_TILE) {
@@ -892,9 +906,10 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_order_rows(OrderArgs a) {
             __syncthreads();
             for (uint32_t j = threadIdx.x; j < tn; j += ORDER_THREADS) {
                 const OrderCell oc = order_cell(a, p, own, j0 + j);
-                const uint32_t cj = oc.mirrored ? a.st_src[oc.slot] : a.st_col[oc.slot];
+                const uint2 kj = cell_key(a, oc);
+                const uint32_t cj = kj.x;
                 s_col[j] = cj;
-                s_hi[j] = order_key_hi(cj, a.st_first[oc.slot], a.canonical);
+                s_hi[j] = order_key_hi(cj, kj.y, a.canonical);
             }
             __syncthreads();
             if (live) {
@@ -907,9 +922,9 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_order_rows(OrderArgs a) {
         }
         if (live) {
             const uint32_t o = out0 + rank;
-            a.c_score[o] = a.st_score[me.slot];
-            a.c_perc[o] = me.mirrored ? a.st_tr[me.slot] : a.st_perc[me.slot];
-            a.c_tr[o] = me.mirrored ? a.st_perc[me.slot] : a.st_tr[me.slot];
+            float v_score, v_perc, v_tr;
+            cell_values(a, me, v_score, v_perc, v_tr);
+            a.c_score[o] = v_score; a.c_perc[o] = v_perc; a.c_tr[o] = v_tr;
             a.c_row[o] = (int32_t) row;
             a.c_col[o] = (int32_t) col;
         }
@@ -936,8 +951,9 @@ __global__ __launch_bounds__(256) void k_order_rows_wave(OrderArgs a) {
         const uint32_t i = s * PDL_WAVE + lane;
         if (s < nslots && i < cnt) {
             me[s] = order_cell(a, p, own, i);
-            col[s] = me[s].mirrored ? a.st_src[me[s].slot] : a.st_col[me[s].slot];
-            const unsigned long long hi = order_key_hi(col[s], a.st_first[me[s].slot], a.canonical);
+            const uint2 km = cell_key(a, me[s]);
+            col[s] = km.x;
+            const unsigned long long hi = order_key_hi(col[s], km.y, a.canonical);
             hi_lo[s] = (uint32_t) hi; hi_hi[s] = (uint32_t) (hi >> 32);
         }
     }
@@ -982,27 +998,37 @@ __global__ __launch_bounds__(256) void k_order_rows_wave(OrderArgs a) {
         const uint32_t i = s * PDL_WAVE + lane;
         if (s < nslots && i < cnt) {
             const uint32_t o = out0 + rank[s];
-            a.c_score[o] = a.st_score[me[s].slot];
-            a.c_perc[o] = me[s].mirrored ? a.st_tr[me[s].slot] : a.st_perc[me[s].slot];
-            a.c_tr[o] = me[s].mirrored ? a.st_perc[me[s].slot] : a.st_tr[me[s].slot];
+            float v_score, v_perc, v_tr;
+            cell_values(a, me[s], v_score, v_perc, v_tr);
+            a.c_score[o] = v_score; a.c_perc[o] = v_perc; a.c_tr[o] = v_tr;
             a.c_row[o] = row;
             a.c_col[o] = (int32_t) col[s];
         }
     }
 }
 
-// mirror mode: hand every staged cell (r, c) to row c.  One wave per source row; the slot inside c's list is
-// drawn with an atomic (the order inside a list is irrelevant: K-order ranks the cells by key).
-__global__ __launch_bounds__(256) void k_mirror_refs(const uint32_t *__restrict__ row_base, const uint32_t *__restrict__ row_cnt,
-                                                     const uint32_t *__restrict__ st_col, const uint32_t *__restrict__ taskpos_of,
-                                                     const uint32_t *__restrict__ mirror_off, uint32_t *__restrict__ mirror_cur,
-                                                     uint32_t n_rows, uint32_t *__restrict__ mirror_ref) {
+// mirror mode: hand every staged cell (r, c) to row c — as row c reads it: column r, perc and tr_perc swapped — by copying
+// it into c's stretch of mcell.  One wave per source row (coalesced reads of its staged cells); the slot inside c's
+// stretch is drawn with an atomic (the order inside a stretch is irrelevant: K-order ranks the cells by key).
+struct MirrorArgs {
+    const uint32_t *row_base, *row_cnt, *task_rows;
+    const float *st_score, *st_perc, *st_tr;
+    const uint32_t *st_col, *st_first, *st_src;
+    const uint32_t *taskpos_of, *mirror_off;
+    uint32_t *mirror_cur;
+    uint32_t n_rows;
+    MCell *mcell;
+};
+__global__ __launch_bounds__(256) void k_mirror_cells(MirrorArgs a) {
     const uint32_t p = blockIdx.x * (256 / PDL_WAVE) + threadIdx.x / PDL_WAVE;
-    if (p >= n_rows) return;
-    const uint32_t base = row_base[p], cnt = row_cnt[p];
+    if (p >= a.n_rows) return;
+    const uint32_t base = a.row_base[p], cnt = a.row_cnt[p], r = a.task_rows[p];
     for (uint32_t i = threadIdx.x & (PDL_WAVE - 1); i < cnt; i += PDL_WAVE) {
-        const uint32_t pc = taskpos_of[st_col[base + i]];
-        if (pc != 0xffffffffu) mirror_ref[mirror_off[pc] + atomicAdd(&mirror_cur[pc], 1u)] = base + i;     // (else: another GPU's row)
+        const uint32_t s = base + i;
+        const uint32_t pc = a.taskpos_of[a.st_col[s]];
+        if (pc == 0xffffffffu) continue;                 // another GPU's row: the cell travels there (k_outbox)
+        const uint32_t dst = a.mirror_off[pc] + atomicAdd(&a.mirror_cur[pc], 1u);
+        a.mcell[dst] = MCell{r, a.st_first[s], a.st_score[s], a.st_tr[s], a.st_perc[s], 0u};
     }
 }
 
@@ -1079,13 +1105,15 @@ __global__ __launch_bounds__(256) void k_inbox_file(InboxArgs a) {
     atomicMax(reinterpret_cast<uint32_t *>(a.MS + (size_t) pc * a.G + a.genome_of[cl.row]), __float_as_uint(cl.score));
     atomicMax(reinterpret_cast<uint32_t *>(a.CM + (size_t) a.local_genome[a.genome_of[cl.column]] * a.N + cl.row), __float_as_uint(cl.score));
 }
-__global__ __launch_bounds__(256) void k_mirror_refs_inbox(const uint32_t *__restrict__ st_col, const uint32_t *__restrict__ taskpos_of,
-                                                           const uint32_t *__restrict__ mirror_off, uint32_t *__restrict__ mirror_cur,
-                                                           uint32_t slot0, uint32_t n, uint32_t *__restrict__ mirror_ref) {
+// ... and the cells received from other GPUs (filed at staging slots slot0 ..: row = the sender's gene, in st_src)
+__global__ __launch_bounds__(256) void k_mirror_cells_inbox(MirrorArgs a, uint32_t slot0, uint32_t n) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const uint32_t pc = taskpos_of[st_col[slot0 + i]];
-    if (pc != 0xffffffffu) mirror_ref[mirror_off[pc] + atomicAdd(&mirror_cur[pc], 1u)] = slot0 + i;
+    const uint32_t s = slot0 + i;
+    const uint32_t pc = a.taskpos_of[a.st_col[s]];
+    if (pc == 0xffffffffu) return;
+    const uint32_t dst = a.mirror_off[pc] + atomicAdd(&a.mirror_cur[pc], 1u);
+    a.mcell[dst] = MCell{a.st_src[s], a.st_first[s], a.st_score[s], a.st_tr[s], a.st_perc[s], 0u};
 }
 
 // work-item descriptors of the LDS join, in processing order (currently task order)
@@ -1306,7 +1334,7 @@ static void score_alloc_cells(pdl_ctx *c, const ScorePlan &pl, unsigned long lon
     DevBuf *st[6] = {&c->st_score, &c->st_perc, &c->st_tr, &c->st_col, &c->st_first, &c->st_src};
     for (int i = 0; i < (pl.mirror ? 6 : 5); i++) { if (keep) st[i]->grow_keep(st_total * 4, c->stream); else st[i]->alloc(st_total * 4); }
     c->c_score.alloc(fcap * 4); c->c_perc.alloc(fcap * 4); c->c_tr.alloc(fcap * 4); c->c_row.alloc(fcap * 4); c->c_col.alloc(fcap * 4);
-    if (pl.mirror) c->mirror_ref.alloc(st_total * 4);
+    if (pl.mirror) c->mirror_ref.alloc(st_total * sizeof(MCell));     // the mirrored cells, copied (one per staged / received cell)
     c->st_cap = cap;
 }
 
@@ -1436,12 +1464,15 @@ static unsigned long long score_order(pdl_ctx *c, const ScorePlan &pl, uint32_t 
     if (pl.mirror) {
         uint32_t *m_off = c->mirror_cnt.as<uint32_t>() + n_rows, *m_cur = m_off + n_rows;
         scan_and_apply(c, n_rows, MirrorCntFlag{d_mcnt}, FinOffApply{m_off}, d_scal + 9);
-        hipLaunchKernelGGL(k_mirror_refs, dim3((n_rows + 3) / 4), dim3(256), 0, st, c->row_base.as<uint32_t>(), c->row_cnt.as<uint32_t>(),
-                           c->st_col.as<uint32_t>(), c->taskpos_of.as<uint32_t>(), m_off, m_cur, n_rows, c->mirror_ref.as<uint32_t>());
-        if (n_inbox)
-            hipLaunchKernelGGL(k_mirror_refs_inbox, dim3((n_inbox + 255) / 256), dim3(256), 0, st, c->st_col.as<uint32_t>(), c->taskpos_of.as<uint32_t>(),
-                               m_off, m_cur, (uint32_t) c->st_cap, n_inbox, c->mirror_ref.as<uint32_t>());
-        o.st_src = c->st_src.as<uint32_t>(); o.mirror_cnt = d_mcnt; o.mirror_off = m_off; o.mirror_ref = c->mirror_ref.as<uint32_t>();
+        MirrorArgs ma{};
+        ma.row_base = c->row_base.as<uint32_t>(); ma.row_cnt = c->row_cnt.as<uint32_t>(); ma.task_rows = c->task_rows.as<uint32_t>();
+        ma.st_score = c->st_score.as<float>(); ma.st_perc = c->st_perc.as<float>(); ma.st_tr = c->st_tr.as<float>();
+        ma.st_col = c->st_col.as<uint32_t>(); ma.st_first = c->st_first.as<uint32_t>(); ma.st_src = c->st_src.as<uint32_t>();
+        ma.taskpos_of = c->taskpos_of.as<uint32_t>(); ma.mirror_off = m_off; ma.mirror_cur = m_cur; ma.n_rows = n_rows;
+        ma.mcell = c->mirror_ref.as<MCell>();
+        hipLaunchKernelGGL(k_mirror_cells, dim3((n_rows + 3) / 4), dim3(256), 0, st, ma);
+        if (n_inbox) hipLaunchKernelGGL(k_mirror_cells_inbox, dim3((n_inbox + 255) / 256), dim3(256), 0, st, ma, (uint32_t) c->st_cap, n_inbox);
+        o.st_src = c->st_src.as<uint32_t>(); o.mirror_cnt = d_mcnt; o.mirror_off = m_off; o.mcell = c->mirror_ref.as<MCell>();
     }
     o.row_base = c->row_base.as<uint32_t>(); o.row_cnt = c->row_cnt.as<uint32_t>(); o.fin_off = c->fin_off.as<uint32_t>();
     o.task_rows = c->task_rows.as<uint32_t>();

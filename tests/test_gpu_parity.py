@@ -135,6 +135,25 @@ def test_staging_overflow_repeats_the_pass(name):
     H.assert_scores_equal_fixture(lambda g: nat.generate_scores_part(g).as_dict(), fx, nat.cost.genomes, f"{name} tiny staging, HBM tier")
 
 
+def test_measurement_options_change_nothing_but_the_timings():
+    """stage_timers = 0 drops the HIP events around the single stages (their fields read 0, the totals and the join's stay);
+    join_grid_pct launches the join's first tier with fewer workgroups.  Neither touches a result."""
+    res, off, gen, k, d = H.load_large("synth_16x1000x300_k5")
+    nat = _native(res, off, gen, k)
+    nat.set_option("stage_timers", 0)
+    nat.set_option("join_grid_pct", 40)
+    nat.preprocess(k, res, off, gen)
+    H.assert_scores_match_digest(lambda g: nat.generate_scores_part(g).as_dict(), d, "no stage timers, 40 % grid")
+    tm = nat.timings()
+    assert tm["sort_rank_ms"] == 0 and tm["order_ms"] == 0 and tm["hist_ms"] == 0
+    assert tm["preprocess_total_ms"] > 0 and tm["score_total_ms"] > 0 and tm["join_ms"] > 0
+    nat.set_option("stage_timers", 1)
+    nat.preprocess(k, res, off, gen)
+    nat.generate_scores_part(0)
+    tm = nat.timings()
+    assert tm["sort_rank_ms"] > 0 and tm["order_ms"] > 0 and tm["join_ms"] >= tm["join_overflow_ms"]
+
+
 def test_errors_mirror_reference_behaviour():
     from pandelos_amd import _lib
     res, off, gen, _, _ = H.load_small("readme4_k2")

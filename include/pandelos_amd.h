@@ -122,6 +122,34 @@ PDL_API int pdl_preprocess_device(pdl_ctx *, const uint8_t *d_residues, const ui
                                   const uint32_t *d_genome_of, uint32_t n_sequences, uint64_t n_residues,
                                   int kvalue, int only_complexity, pdl_cost *out_cost);
 
+/* ---- ingest: .faa -> HBM (the Java side's PangeneIData.readFromFile, PangeneIData.java:30-75, and calculate_k.py:9-30) --
+ * One pass over the mapped file: readLine's terminators (\n, \r, \r\n), String.trim, blank lines skipped, header / sequence
+ * alternating, genome = the header's text before the first tab, ids dense in first-seen order; a header with fewer than three
+ * tab-separated fields fails (the reader indexes cc[1], cc[2]).  Sequence bytes are copied once, into pinned staging buffers
+ * that leave for the device while the parser goes on.  k_suggested is what calculate_k.py prints for the same file (raw line
+ * parity, str.strip, entropy summed in first-seen letter order; 0 where the script would divide by zero). */
+typedef struct {
+    uint64_t file_bytes;
+    uint64_t residues;             /* R */
+    uint32_t sequences, genomes;   /* N, G */
+    int32_t k_suggested;
+    uint32_t reserved;
+    double parse_ms;               /* wall time: open -> last byte on the device (pdl_scan_faa: -> parsed) */
+    const uint64_t *offsets;       /* host [sequences + 1], owned by the context until its next ingest (pdl_scan_faa: NULL) */
+    const uint32_t *genome_of;     /* host [sequences] */
+    const uint8_t *d_residues;     /* device, owned by the context: the arguments of pdl_preprocess_device / pdl_dist_preprocess_begin */
+    const uint64_t *d_offsets;
+    const uint32_t *d_genome_of;
+} pdl_ingest;
+PDL_API int pdl_ingest_faa(pdl_ctx *, const char *path, pdl_ingest *out);
+/* genome names in id order (PangeneIData.genomeNames); NULL when out of range */
+PDL_API const char *pdl_ingest_genome_name(const pdl_ctx *, uint32_t genome);
+/* preprocessSequences on the ingested input (no copy, no read-back of the genome ids) */
+PDL_API int pdl_preprocess_ingested(pdl_ctx *, int kvalue, int only_complexity, pdl_cost *out_cost /* may be NULL */);
+/* The same parser without a device or a context, into caller buffers (each may be NULL: count only).  Errors: pdl_last_error(NULL). */
+PDL_API int pdl_scan_faa(const char *path, pdl_ingest *out, uint8_t *residues, uint64_t cap_residues, uint64_t *offsets /* [cap_sequences + 1] */,
+                         uint32_t *genome_of, uint32_t cap_sequences);
+
 /* "Genome g cost = ..." (library.cpp:535-538) */
 PDL_API int pdl_genome_cost(const pdl_ctx *, uint32_t genome, uint64_t *out_cost);
 /* Per-gene cost (computation_costs[].total_visited, library.cpp:327) and k-mer count (kseq_lengths, :250-262) */

@@ -74,6 +74,13 @@ class PdlDistOutbox(C.Structure):
     _fields_ = [("d_cells", C.c_void_p), ("counts", C.POINTER(C.c_uint64)), ("total", C.c_uint64)]
 
 
+class PdlIngest(C.Structure):
+    _fields_ = [("file_bytes", C.c_uint64), ("residues", C.c_uint64), ("sequences", C.c_uint32), ("genomes", C.c_uint32),
+                ("k_suggested", C.c_int32), ("reserved", C.c_uint32), ("parse_ms", C.c_double),
+                ("offsets", C.POINTER(C.c_uint64)), ("genome_of", C.POINTER(C.c_uint32)),
+                ("d_residues", C.c_void_p), ("d_offsets", C.c_void_p), ("d_genome_of", C.c_void_p)]
+
+
 DIST_CELL_BYTES = 24      # pdl_dist_cell: 3 x f32 + 3 x u32
 
 
@@ -83,7 +90,8 @@ EXPORTS = ("pdl_create", "pdl_destroy", "pdl_last_error", "pdl_preprocess", "pdl
            "pdl_free_scores", "pdl_scores_counts", "pdl_get_dictionary", "pdl_get_rank_table", "pdl_get_timings",
            "pdl_version", "pdl_set_option", "pdl_dist_preprocess_begin", "pdl_dist_preprocess_finish",
            "pdl_dist_genome_owner", "pdl_dist_score_begin", "pdl_dist_score_finish", "pdl_copy_device",
-           "pdl_compute_edges", "pdl_free_edges")
+           "pdl_compute_edges", "pdl_free_edges", "pdl_ingest_faa", "pdl_ingest_genome_name", "pdl_preprocess_ingested",
+           "pdl_scan_faa")
 
 _lib = None
 
@@ -132,5 +140,9 @@ def load():
     lib.pdl_copy_device.argtypes = [vp, vp, vp, u64]; lib.pdl_copy_device.restype = i32
     lib.pdl_compute_edges.argtypes = [vp, u32, C.POINTER(PdlEdges)]; lib.pdl_compute_edges.restype = i32
     lib.pdl_free_edges.argtypes = [C.POINTER(PdlEdges)]; lib.pdl_free_edges.restype = None
+    lib.pdl_ingest_faa.argtypes = [vp, C.c_char_p, C.POINTER(PdlIngest)]; lib.pdl_ingest_faa.restype = i32
+    lib.pdl_ingest_genome_name.argtypes = [vp, u32]; lib.pdl_ingest_genome_name.restype = C.c_char_p
+    lib.pdl_preprocess_ingested.argtypes = [vp, i32, i32, C.POINTER(PdlCost)]; lib.pdl_preprocess_ingested.restype = i32
+    lib.pdl_scan_faa.argtypes = [C.c_char_p, C.POINTER(PdlIngest), vp, u64, vp, vp, u32]; lib.pdl_scan_faa.restype = i32
     _lib = lib
     return lib

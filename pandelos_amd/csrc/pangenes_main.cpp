@@ -3,8 +3,7 @@
 //
 //   ig/infoasys/cli/pangenes/Cli.java:13-57          flags -i/--input -k/--kvalue -o/--output (required), -c/--complexity,
 //                                                    -j/--threads (accepted, unused: the device pass is not threaded), -h
-//   ig/infoasys/cli/pangenes/PangeneIData.java:30-75 .faa reader (trim, skip blank lines, header/sequence alternate,
-//                                                    genome ids in first-seen order)
+//   ig/infoasys/cli/pangenes/PangeneIData.java:30-75 .faa reader: the library's streaming ingest (pdl_ingest_faa, pdl_ingest.hip)
 //   ig/infoasys/cli/pangenes/Pangenes.java:60-183    per-genome task: bidirectional-best-hit filter, both phases
 //   ig/infoasys/cli/pangenes/PangeneNet.java:49-62,159-179   first insert per (src,dst) wins; undirected save in
 //                                                    java.util.HashMap iteration order, edges by ascending destination
@@ -18,7 +17,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <fstream>
 #include <limits>
 #include <map>
 #include <string>
@@ -26,13 +24,6 @@
 #include <vector>
 
 namespace {
-
-std::string java_trim(const std::string &s) {       // String.trim(): strips chars <= ' ' at both ends
-    size_t b = 0, e = s.size();
-    while (b < e && (unsigned char) s[b] <= ' ') b++;
-    while (e > b && (unsigned char) s[e - 1] <= ' ') e--;
-    return s.substr(b, e - b);
-}
 
 // Double.toString of a float widened to double: shortest round-trip digits; decimal layout for 1e-3 <= x < 1e7,
 // "d.dddE-n" otherwise
@@ -89,7 +80,7 @@ void usage() {
 int main(int argc, char **argv) {
     std::string input, output;
     int k = 0;
-    bool have_k = false, complexity = false;
+    bool have_k = false, complexity = false, k_auto = false;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto val = [&]() -> const char * { return i + 1 < argc ? argv[++i] : nullptr; };
@@ -97,7 +88,10 @@ int main(int argc, char **argv) {
         else if (a == "-c" || a == "--complexity") complexity = true;
         else if (a == "-i" || a == "--input") { const char *v = val(); if (v) input = v; }
         else if (a == "-o" || a == "--output") { const char *v = val(); if (v) output = v; }
-        else if (a == "-k" || a == "--kvalue") { const char *v = val(); if (v) { k = atoi(v); have_k = true; } }
+        else if (a == "-k" || a == "--kvalue") {
+            const char *v = val();
+            if (v) { k_auto = strcmp(v, "auto") == 0; k = k_auto ? 0 : atoi(v); have_k = true; }      // "auto" (not in the reference): calculate_k.py's value, computed by the ingest pass
+        }
         else if (a == "-j" || a == "--threads") { (void) val(); }
         else { input.clear(); break; }
     }
@@ -107,40 +101,21 @@ int main(int argc, char **argv) {
         return 1;
     }
 
-    // ---- PangeneIData.readFromFile ----------------------------------------------------------------------
-    std::vector<uint8_t> residues;
-    std::vector<uint64_t> offsets(1, 0);
-    std::vector<uint32_t> genome_of;
-    std::unordered_map<std::string, uint32_t> genome_id;
-    {
-        std::ifstream in(input);
-        if (!in) { fprintf(stderr, "java.io.FileNotFoundException: %s\n", input.c_str()); return 0; }   // Pangenes.java:26-31
-        std::string line, genome;
-        bool name_line = true;
-        while (std::getline(in, line)) {
-            if (!line.empty() && line.back() == '\r') line.pop_back();
-            const std::string t = java_trim(line);
-            if (t.empty()) continue;
-            if (name_line) {
-                genome = t.substr(0, t.find('\t'));
-            } else {
-                residues.insert(residues.end(), t.begin(), t.end());
-                offsets.push_back(residues.size());
-                auto it = genome_id.find(genome);
-                if (it == genome_id.end()) it = genome_id.emplace(genome, (uint32_t) genome_id.size()).first;
-                genome_of.push_back(it->second);
-            }
-            name_line = !name_line;
-        }
-    }
-    const uint32_t n = (uint32_t) genome_of.size();
-    const uint32_t G = (uint32_t) genome_id.size();
-
+    // ---- PangeneIData.readFromFile: the library's streaming ingest (pdl_ingest.hip) — the file goes to HBM as it is parsed ----
     pdl_ctx *ctx = pdl_create(nullptr);
     if (!ctx) { fprintf(stderr, "pandelos_amd: %s\n", pdl_last_error(nullptr)); return 1; }
+    pdl_ingest ing;
+    if (pdl_ingest_faa(ctx, input.c_str(), &ing) != PDL_OK) {
+        // Pangenes.java:26-31: the reader's exception is printed and main returns
+        fprintf(stderr, "java.io.FileNotFoundException / reader: %s\n", pdl_last_error(ctx));
+        pdl_destroy(ctx);
+        return 0;
+    }
+    const uint32_t G = ing.genomes;
+    if (k_auto) { k = ing.k_suggested; printf("k = %d\n", k); }                // calculate_k.py:30 (the line pandelos.sh:67-68 greps for)
     if (k <= 0) { printf("K value must be greater than 0."); return 1; }      // library.cpp:90-93
     pdl_cost cost;
-    if (pdl_preprocess(ctx, residues.data(), offsets.data(), genome_of.data(), n, k, complexity ? 1 : 0, &cost) != PDL_OK) {
+    if (pdl_preprocess_ingested(ctx, k, complexity ? 1 : 0, &cost) != PDL_OK) {
         fprintf(stderr, "pandelos_amd: %s\n", pdl_last_error(ctx));
         return 1;
     }

@@ -71,6 +71,8 @@ void pdl_destroy(pdl_ctx *c) {
     if (c->copy_stream) (void) hipStreamDestroy(c->copy_stream);
     if (c->gen_pin) (void) hipHostFree(c->gen_pin);
     if (c->ev_gen) (void) hipEventDestroy(c->ev_gen);
+    for (int i = 0; i < 2; i++) { if (c->ing_pin[i]) (void) hipHostFree(c->ing_pin[i]); if (c->ing_ev[i]) (void) hipEventDestroy(c->ing_ev[i]); }
+    if (c->ing_stream) (void) hipStreamDestroy(c->ing_stream);
     delete c;
 }
 
@@ -125,9 +127,9 @@ void pdl_finish_layout(pdl_ctx *c) {
     c->layout_deferred = false;
     layout_and_shard(c);
 }
-extern "C" {
+void pdl_set_create_error(const std::string &msg) { g_create_error = msg; }
 
-static int preprocess_common(pdl_ctx *c, uint32_t n, uint64_t n_res, int k, int only_complexity, pdl_cost *out_cost) {
+int pdl_preprocess_common(pdl_ctx *c, uint32_t n, uint64_t n_res, int k, int only_complexity, pdl_cost *out_cost) {
     PDL_GUARD_BEGIN
     PDL_HIP(hipSetDevice(c->device));
     c->preprocessed = false; c->scored = false; c->tasks_ready = false;      // the genome shard, if one was set, stays in force
@@ -143,6 +145,11 @@ static int preprocess_common(pdl_ctx *c, uint32_t n, uint64_t n_res, int k, int 
     return PDL_OK;
     PDL_GUARD_END(c)
 }
+static int preprocess_common(pdl_ctx *c, uint32_t n, uint64_t n_res, int k, int only_complexity, pdl_cost *out_cost) {
+    return pdl_preprocess_common(c, n, n_res, k, only_complexity, out_cost);
+}
+
+extern "C" {
 
 // device-resident input: genome ids come to the host (task layout), and the two ends of the offsets are checked against
 // n_res (a wrong n_res would make the ranking kernels read past the residues; ascending order is checked by K-len)

@@ -126,6 +126,17 @@ struct pdl_ctx {
     uint64_t R = 0, M = 0, U = 0, Ushared = 0, NG = 0, P = 0, sum_kseq = 0, max_kseq = 0, min_kseq = 0;
     RankParams rp{};
 
+    // K-ingest (pdl_ingest.hip): the input a .faa file was parsed into, and the two pinned staging buffers it travelled through
+    DevBuf ing_res, ing_off, ing_gen;
+    uint8_t *ing_pin[2] = {nullptr, nullptr};
+    hipEvent_t ing_ev[2] = {nullptr, nullptr};
+    hipStream_t ing_stream = nullptr;
+    std::vector<uint64_t> ing_h_off;
+    std::vector<uint32_t> ing_h_gen;
+    std::vector<std::string> ing_genome_names;
+    uint64_t ing_R = 0;
+    bool ingested = false;
+
     // per sequence
     DevBuf kseq_len;      // u32 [N]
     DevBuf kmer_off;      // u64 [N+1]

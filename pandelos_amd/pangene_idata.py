@@ -8,12 +8,14 @@ flattened form the C ABI takes (``residues`` / ``offsets`` / ``genome_of``).
 """
 from __future__ import annotations
 
+import re
 from dataclasses import dataclass, field
 from typing import List
 
 import numpy as np
 
 _JAVA_TRIM = bytes(range(0x21))  # String.trim() strips chars <= ' '
+_READLINE = re.compile(rb"\r\n|\r|\n")
 
 
 @dataclass
@@ -31,24 +33,27 @@ class PangeneIData:
         name_line = True
         genome_name = seq_name = product = None
         with open(path, "rb") as f:
-            for raw in f:
-                line = raw.rstrip(b"\r\n").strip(_JAVA_TRIM)
-                if not line:
-                    continue
-                if name_line:
-                    cc = line.decode("latin-1").split("\t")
-                    # Java indexes cc[1], cc[2] unconditionally (PangeneIData.java:49-51)
-                    genome_name, seq_name, product = cc[0], cc[1], cc[2]
-                else:
-                    d.sequences.append(line)
-                    d.sequenceName.append(seq_name)
-                    gid = genome_id.get(genome_name)
-                    if gid is None:
-                        gid = len(genome_id)
-                        genome_id[genome_name] = gid
-                    d.sequenceGenome.append(gid)
-                    d.sequenceDescription.append(product)
-                name_line = not name_line
+            raw_lines = _READLINE.split(f.read())                # BufferedReader.readLine: \n, \r and \r\n end a line
+        if raw_lines and raw_lines[-1] == b"":
+            raw_lines.pop()
+        for raw in raw_lines:
+            line = raw.strip(_JAVA_TRIM)
+            if not line:
+                continue
+            if name_line:
+                cc = line.decode("latin-1").split("\t")
+                # Java indexes cc[1], cc[2] unconditionally (PangeneIData.java:49-51)
+                genome_name, seq_name, product = cc[0], cc[1], cc[2]
+            else:
+                d.sequences.append(line)
+                d.sequenceName.append(seq_name)
+                gid = genome_id.get(genome_name)
+                if gid is None:
+                    gid = len(genome_id)
+                    genome_id[genome_name] = gid
+                d.sequenceGenome.append(gid)
+                d.sequenceDescription.append(product)
+            name_line = not name_line
         d.genomeNames = [None] * len(genome_id)
         for name, gid in genome_id.items():
             d.genomeNames[gid] = name
@@ -67,6 +72,24 @@ class PangeneIData:
         ng = (max(d.sequenceGenome) + 1) if d.sequenceGenome else 0
         d.genomeNames = [f"G{g}" for g in range(ng)]
         return d
+
+    @staticmethod
+    def scan(path) -> dict:
+        """The library's own parser (``pdl_scan_faa``: the one ``pdl_ingest_faa`` streams to the device with) run on the
+        host only -> flattened arrays + sizes + the k ``calculate_k.py`` prints for the file.  Needs no GPU."""
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        ing = _lib.PdlIngest()
+        rc = lib.pdl_scan_faa(str(path).encode(), C.byref(ing), None, 0, None, None, 0)
+        if rc != _lib.PDL_OK:
+            raise _lib.PdlError(rc, lib.pdl_last_error(None).decode())
+        res = np.zeros(ing.residues, np.uint8); off = np.zeros(ing.sequences + 1, np.uint64); gen = np.zeros(ing.sequences, np.uint32)
+        rc = lib.pdl_scan_faa(str(path).encode(), C.byref(ing), res.ctypes.data, len(res), off.ctypes.data, gen.ctypes.data, len(gen))
+        if rc != _lib.PDL_OK:
+            raise _lib.PdlError(rc, lib.pdl_last_error(None).decode())
+        return {"residues": res, "offsets": off, "genome_of": gen, "sequences": ing.sequences, "genomes": ing.genomes,
+                "k_suggested": ing.k_suggested, "file_bytes": ing.file_bytes}
 
     # -- flattened form for the C ABI ----------------------------------------------------------
     def flatten(self):

@@ -97,6 +97,24 @@ class PangeneNative:
                                       int(only_complexity), C.byref(self.cost))
         self._check(rc)
 
+    def ingest_faa(self, path) -> dict:
+        """`.faa` -> HBM in one pass (``pdl_ingest_faa``: PangeneIData.readFromFile + calculate_k.py on the way, pinned
+        staging buffers, copies overlapped with the parse).  -> sizes, ``k_suggested``, ``genome_names``, host ``offsets`` /
+        ``genome_of`` and the device pointers ``preprocess_ingested`` works on."""
+        ing = _lib.PdlIngest()
+        self._check(self._lib.pdl_ingest_faa(self._ctx, str(path).encode(), C.byref(ing)))
+        n = ing.sequences
+        return {"file_bytes": ing.file_bytes, "residues": ing.residues, "sequences": n, "genomes": ing.genomes,
+                "k_suggested": ing.k_suggested, "parse_ms": ing.parse_ms,
+                "offsets": _np_copy(ing.offsets, np.uint64, n + 1), "genome_of": _np_copy(ing.genome_of, np.uint32, n),
+                "genome_names": [self._lib.pdl_ingest_genome_name(self._ctx, g).decode("latin-1") for g in range(ing.genomes)],
+                "d_residues": ing.d_residues or 0, "d_offsets": ing.d_offsets or 0, "d_genome_of": ing.d_genome_of or 0}
+
+    def preprocess_ingested(self, k, only_complexity=False):
+        """preprocessSequences on what ``ingest_faa`` left in HBM."""
+        self.cost = _lib.PdlCost()
+        self._check(self._lib.pdl_preprocess_ingested(self._ctx, int(k), int(only_complexity), C.byref(self.cost)))
+
     def _check(self, rc):
         if rc != _lib.PDL_OK:
             raise _lib.PdlError(rc, self._lib.pdl_last_error(self._ctx).decode())

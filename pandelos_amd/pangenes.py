@@ -21,7 +21,6 @@ from typing import List, Sequence
 
 import numpy as np
 
-from .pangene_idata import PangeneIData
 from .scores import Scores
 
 INT32_MAX = np.iinfo(np.int32).max
@@ -140,20 +139,21 @@ def main(argv: Sequence[str] | None = None) -> int:
             ap.print_help()
             return 1
         return 0
+    from . import _lib
     from .pangene_native import PangeneNative
+    nativ = PangeneNative.open()
     try:
-        pid = PangeneIData.read_from_file(args.input)           # Pangenes.java:26-31
-    except Exception as e:                                      # the reference prints the stack trace and returns
+        ing = nativ.ingest_faa(args.input)                      # Pangenes.java:26-31 (PangeneIData.readFromFile), streamed to HBM
+    except _lib.PdlError as e:                                  # the reference prints the stack trace and returns
         print(f"{type(e).__name__}: {e}", file=sys.stderr)
         return 0
-    if args.complexity:
-        PangeneNative.print_complexity(args.kvalue, pid)        # :33-36
-        return 0
-    nativ = PangeneNative(args.kvalue, pid)                     # :39
+    nativ.preprocess_ingested(args.kvalue, only_complexity=args.complexity)      # :39 (-c: PangeneNative.printComplexity, :33-36)
     print("------------\nCOMPUTATIONAL COSTS: ")
     print(f"Total cost: {nativ.cost.total_cost} lookups")
     print(f"Linear ratio: {nativ.cost.linear_ratio:g}\n------------\n")
-    lines = run(nativ, len(pid.genomeNames))
+    if args.complexity:
+        return 0
+    lines = run(nativ, ing["genomes"])
     print("----------")
     print(f"writing into {args.output}")
     with open(args.output, "w") as f:

@@ -6,8 +6,9 @@
 #     (pandelos_amd/lib/pangenes; the JVM route is to point -Djava.library.path at pandelos_amd/lib instead, see
 #     INTEGRATION.md).
 #   * With PANDELOS_PATH set to a PanDelos checkout, k selection and de-clustering are the reference's own scripts
-#     (calculate_k.py, netclu_ng.py — needs networkx); without it, this repository's restatements of the two
-#     (pandelos_amd/calculate_k.py, pandelos_amd/netclu.py), which the tests pin to the reference's outputs.
+#     (calculate_k.py, netclu_ng.py — needs networkx); without it, k comes from the native host's own ingest pass
+#     (-k auto: pdl_ingest_faa computes calculate_k.py's value on the way) and de-clustering from pandelos_amd/netclu.py;
+#     the tests pin both to the reference's outputs.
 sdir="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 ref="${PANDELOS_PATH:-}"
 idb="$1"; oprefix="$2"
@@ -18,13 +19,14 @@ dnet="${tmp}.net"; clus="${oprefix}.clus"
 echo "calculating k ..."
 if [ -n "$ref" ]; then
     python3 "$ref/calculate_k.py" "$idb" > "$tmp"
+    k=$(grep -E "^k =" "$tmp" | sed s/k\ =\ //g)
 else
-    PYTHONPATH="$sdir" python3 -m pandelos_amd.calculate_k "$idb" > "$tmp"
+    k=auto      # the native host's ingest pass computes calculate_k.py's value while the file streams to the GPU and prints "k = N"
 fi
-k=$(grep -E "^k =" "$tmp" | sed s/k\ =\ //g)
-echo "k = $k"
+[ "$k" != auto ] && echo "k = $k"
 echo "clustering ..."
 "$sdir/pandelos_amd/lib/pangenes" -i "$idb" -k $k -o "$dnet" > "$tmp" || { echo "ERROR: the native stage failed"; cat "$tmp"; rm -f "$tmp" "$dnet"; exit 1; }
+[ "$k" = auto ] && grep -E "^k = " "$tmp"
 echo "de-clustering ..."
 if [ -n "$ref" ]; then
     python3 "$ref/netclu_ng.py" "$idb" "$dnet" >> "$tmp"

@@ -25,8 +25,11 @@ shards over 8 GPUs) at the same N, so that a 1/2/4/8 series has a workload large
 Extra objects on the JSON line:
   roofline             dominant kernel = K-join; achieved = algorithmic bytes of the join launch (8 B per lookup as the
                        reference counts them + 20 B per emitted cell + 8 B per (gene, genome) maximum) / its HIP-event
-                       duration measured inside the library on the launch stream.  `traffic` comes from the committed
-                       rocprofv3 PMC profile of this workload (counters cannot be read by the run itself).
+                       duration measured inside the library on the launch stream.  `traffic` = HBM bytes of the same
+                       launch from the PMC counters, measured by THIS run at N = 1: two child runs of this script under
+                       `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, FETCH doubled on gfx950, as
+                       MI355X_MICROARCH.md prescribes) after the timed region; `--no-traffic` skips them, and without
+                       rocprofv3 the committed profile of the workload is quoted instead (`traffic_source` says which).
   roofline_whole_path  the same for the whole step: SURVEY.md §8d's bytes_alg / step time.
   cpu_baseline         the reference's own library.cpp (oracle/_ref, kind "reference") — or the C restatement
                        (kind "port") when that build is absent — timed on this host's cores on the same workload.
@@ -77,6 +80,45 @@ def cpu_baseline(gs, k, pairs, max_threads):
     return {"value": pairs / (t2 - t0), "unit": "gene-pairs/s", "cores": threads, "kind": "port",
             "sample": sample, "preprocess_s": t1 - t0, "scores_s": t2 - t1,
             "lookups_per_s": o.total_cost / max(t2 - t1, 1e-9)}
+
+
+def measure_traffic(config: str, options):
+    """HBM-side bytes per K-join launch, from the counters: FETCH_SIZE and WRITE_SIZE do not fit one pass (TCC slots), so two
+    child runs of this script under rocprofv3, each with --kernel-trace only beside --pmc.  Units are KiB; on gfx950
+    FETCH_SIZE tallies 128-byte requests as 64 -> doubled (MI355X_MICROARCH.md, HBM section).  -> (bytes, how) or (None, why)."""
+    import csv
+    import glob
+    import shutil
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    if "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCPROFILER")) for k in os.environ):
+        return None, "this run is itself being profiled"
+    per_launch = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            cmd = [prof, "--pmc", counter, "--kernel-trace", "-d", td, "--output-format", "csv", "--", sys.executable,
+                   str(Path(__file__).resolve()), "--steps", "2", "--warmup", "1", "--config", config, "--no-cpu-baseline", "--no-scale-set",
+                   "--no-host-path", "--no-traffic"] + [x for o in options for x in ("--option", o)]
+            try:
+                r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=300)
+            except subprocess.TimeoutExpired:
+                return None, f"rocprofv3 --pmc {counter}: timed out"
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter}: exit {r.returncode}"
+            tot, launches = {}, {}
+            for f in glob.glob(td + "/**/*counter_collection.csv", recursive=True):
+                for row in csv.DictReader(open(f)):
+                    name = row["Kernel_Name"]
+                    if row["Counter_Name"] == counter and "k_join" in name:
+                        tot[name] = tot.get(name, 0.0) + float(row["Counter_Value"])
+                        launches.setdefault(name, set()).add(row["Dispatch_Id"])
+            if not tot:
+                return None, f"rocprofv3 --pmc {counter}: no k_join dispatch in the output"
+            per_launch[counter] = sum(tot[n] / len(launches[n]) for n in tot)     # a scoring pass launches each tier's kernel once
+    return ((2.0 * per_launch["FETCH_SIZE"] + per_launch["WRITE_SIZE"]) * 1024.0,
+            "measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two child passes of this script, FETCH doubled (gfx950)")
 
 
 def launch_ranks(args) -> int:
@@ -218,6 +260,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-scale-set", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic")
     ap.add_argument("--cpu-threads", type=int, default=64)
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="pdl_set_option on every context (experiments)")
     args = ap.parse_args()
@@ -278,16 +321,20 @@ def main():
     # profiles/*_pmc_traffic_join.json).  null when no profile of this workload/sharding is on file.
     traffic, traffic_src = None, None
     if n_gpus == 1 and not args.faa:
-        for pf in sorted((ROOT / "profiles").glob("r*b_pmc_traffic_join.json"), reverse=True):
-            try:
-                prof = json.loads(pf.read_text())
-                if prof.get("workload") == args.config:
-                    traffic = sum(v.get("hbm_bytes_per_launch_corrected", 0.0) for kname, v in prof["kernels"].items()
-                                  if "k_join" in kname)
-                    traffic_src = f"profiles/{pf.name}"
-                    break
-            except Exception:
-                pass
+        if not args.no_traffic:
+            traffic, traffic_src = measure_traffic(args.config, args.option)
+        if traffic is None:
+            why = traffic_src
+            for pf in sorted((ROOT / "profiles").glob("r*b_pmc_traffic_join.json"), reverse=True):
+                try:
+                    prof = json.loads(pf.read_text())
+                    if prof.get("workload") == args.config:
+                        traffic = sum(v.get("hbm_bytes_per_launch_corrected", 0.0) for kname, v in prof["kernels"].items()
+                                      if "k_join" in kname)
+                        traffic_src = f"profiles/{pf.name} (committed profile" + (f"; live measurement: {why})" if why else ")")
+                        break
+                except Exception:
+                    pass
 
     sharding = ("whole dataset on one GPU" if n_gpus == 1 else
                 f"{n_gpus} ranks: rank-interval dictionary build + all-gather of the runs, genomes dealt by lookups above the diagonal, "

@@ -121,6 +121,12 @@ class DistributedPangenes:
         import os
         self.p2p_gather = os.environ.get("PDL_DIST_GATHER", "p2p") != "broadcast"     # how the runs are gathered on device tensors
 
+    def _sync(self):
+        """The collectives run on torch's current stream of the device; the library works on its own: wait on the host."""
+        if self.on_device and getattr(self.dev, "type", "cpu") == "cuda":
+            import torch
+            torch.cuda.current_stream(self.dev).synchronize()
+
     # exchange of the dictionary runs: full[offs[p] : offs[p+1]] <- rank p's run, for every p
     def _all_gather_runs(self, full, offs):
         import torch
@@ -172,8 +178,7 @@ class DistributedPangenes:
         if records:
             nat.copy_device(full.data_ptr() + int(offs[r]) * 8, ptr, records * 8)
         self._all_gather_runs(full, offs)
-        if self.on_device:
-            torch.cuda.current_stream(self.dev).synchronize()
+        self._sync()
         self.exchange_s["dictionary"] = time.perf_counter() - t0
         nat.dist_preprocess_finish(full.data_ptr(), total, genome_weights=weights, keepalive=full)
         return nat.cost
@@ -198,7 +203,7 @@ class DistributedPangenes:
         if self.on_device:
             dist.all_to_all_single(recv[:n_in], send[:n_out], output_split_sizes=[int(x) for x in recv_counts],
                                    input_split_sizes=[int(x) for x in send_counts])
-            torch.cuda.current_stream(self.dev).synchronize()
+            self._sync()
         else:
             h_recv = torch.empty((n_in, 6), dtype=torch.int32)
             dist.all_to_all_single(h_recv, send[:n_out].cpu(), output_split_sizes=[int(x) for x in recv_counts],

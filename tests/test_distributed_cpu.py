@@ -108,15 +108,21 @@ class _FakeRank:
         self.seen["inbox"] = keepalive[:n].clone()
 
 
-def _exchange_worker(rank, world, port, out):
+def _exchange_worker(rank, world, port, out, flow="host"):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    if flow == "broadcast":
+        os.environ["PDL_DIST_GATHER"] = "broadcast"
+    else:
+        os.environ.pop("PDL_DIST_GATHER", None)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         fake = _FakeRank(rank, world)
-        dp = D.DistributedPangenes(fake, torch.device("cpu"), device_collectives=False)
+        # flow "p2p" / "broadcast": the branch RCCL runs on device tensors (point-to-point gather of the runs in place,
+        # all-to-all straight out of / into the exchange buffers), here on CPU tensors over gloo
+        dp = D.DistributedPangenes(fake, torch.device("cpu"), device_collectives=flow != "host")
         t = torch.zeros(1)
         dp.preprocess(3, t, t, t, 1, 1)
         dp.score_all()
@@ -126,14 +132,14 @@ def _exchange_worker(rank, world, port, out):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world", [2, 3])
-def test_driver_exchanges_runs_and_cells_in_rank_order(world):
+@pytest.mark.parametrize("world,flow", [(2, "host"), (3, "host"), (2, "p2p"), (3, "p2p"), (4, "p2p"), (3, "broadcast")])
+def test_driver_exchanges_runs_and_cells_in_rank_order(world, flow):
     import queue
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, out)) for r in range(world)]
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, out, flow)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}

@@ -7,7 +7,7 @@ tag=${1:-rXX}
 export TMPDIR=/tmp
 out=gpurun_out
 mkdir -p $out
-args="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-scale-set --no-host-path"
+args="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-scale-set --no-host-path --no-traffic"
 i=0
 for set in "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TCP_LATENCY_sum TCP_TOTAL_READ_sum" \
            "TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum" \

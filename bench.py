@@ -220,7 +220,7 @@ class Runner:
         stage = {"preprocess": mean(pre_ms), "score": mean(score_ms), "hist": tm["hist_ms"], "rank": tm["rank_ms"],
                  "sort_rank": tm["sort_rank_ms"], "dict": tm["dict_ms"], "sort_seq": tm["sort_seq_ms"], "ranges": tm["ranges_ms"],
                  "join": tm["join_ms"], "join_overflow": tm["join_overflow_ms"], "order": tm["order_ms"],
-                 "tier2_rows": tm["tier2_rows"], "overflow_rows": tm["overflow_rows"]}
+                 "tier2_rows": tm["tier2_rows"], "overflow_rows": tm["overflow_rows"], "aside_reloads": tm["aside_reloads"]}
         if self.dp is not None:
             stage.update({"dist_begin": tm["dist_begin_ms"], "dist_finish": tm["dist_finish_ms"], "dist_score_begin": tm["dist_score_begin_ms"],
                           "dist_score_finish": tm["dist_score_finish_ms"], "exchange_dictionary_wall": mean(xd), "exchange_cells_wall": mean(xc),

@@ -102,6 +102,8 @@ typedef struct {
     float dist_score_begin_ms, dist_score_finish_ms;
     uint64_t walked_lookups;       /* postings the join actually read: each unordered pair of a group once when rows only meet the genes above them */
     uint64_t outbox_cells, inbox_cells;
+    uint64_t aside_reloads;        /* join, filter tier: entries of a put-aside list that did not yet show what the wave had stored there
+                                      when it first read them back (they are loaded again until they do) */
 } pdl_timings;
 
 PDL_API pdl_ctx *pdl_create(const pdl_config *cfg /* may be NULL */);

@@ -197,7 +197,7 @@ struct pdl_ctx {
     DevBuf glb_table;     // HBM tables of the overflow pass
     bool glb_clean = false;   // all-zero (k_join_hbm leaves them that way)
     DevBuf row_desc2;     // descriptors of the rows handed from tier 1 to tier 2
-    DevBuf st_src, mirror_cnt, mirror_ref;   // mirror mode (see pdl_join.hip); mirror_ref: the mirrored cells (MCell), per row
+    DevBuf mirror_cnt, mirror_ref;   // mirror mode (see pdl_join.hip); mirror_ref: the mirrored cells (MCell), per row
     DevView taskpos_of;                      // u32 [N] task position of every gene (0xffffffff: not a row of this context)
     std::vector<uint32_t> h_fin;
     bool tasks_ready = false;  // task layout uploaded for the current shard

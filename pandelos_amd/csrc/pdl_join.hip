@@ -59,7 +59,6 @@ struct JoinArgs {
     uint32_t *row_base, *row_cnt;  // [n_task_rows]
     float *st_score, *st_perc, *st_tr;
     uint32_t *st_col, *st_first;
-    uint32_t *st_src;              // mirror mode: gene id of the row that produced the staged cell
     uint32_t mirror;               // 1: ranges hold only columns above the row; every cell (r,c) also stands for (c,r)
     const uint32_t *taskpos_of;    // mirror mode: task position of every gene (0xffffffff: the gene is another GPU's row)
     const uint32_t *local_genome;  // mirror mode: index of every genome in this context's shard (CM row)
@@ -75,8 +74,10 @@ struct JoinArgs {
 #ifdef PDL_JOIN_PHASES
     unsigned long long *phase;     // diagnostic build (-DPDL_JOIN_PHASES): time the first thread of every workgroup spends in the phases of a row (100-MHz ticks, summed)
 #endif
-    unsigned long long *defer;     // filter tiers: per workgroup, the first light sightings of the row in hand {column, 0xffffffff - group key}
+    uint4 *defer;                  // filter tiers: per workgroup, the first light sightings of the row in hand {column, 0xffffffff - group key, row, launch}
     uint32_t defer_cap;            // entries per workgroup; a row with more goes to the next tier
+    uint32_t *reload_count;        // entries that were not there at the first look (diagnostic, pdl_timings.aside_reloads)
+    uint32_t defer_serial;         // this launch's number: with the row it makes an entry recognisable as written for THIS row
     // HBM tables (k_join_hbm only): per workgroup acc u64[N], first u32[N], touched u32[N], emit u32[N]
     unsigned long long *hbm_acc;
     uint32_t *hbm_u32;
@@ -147,6 +148,19 @@ __device__ __forceinline__ uint32_t ld_agent(const uint32_t *p) { return __hip_a
 __device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// 16-byte loads that L1 never serves (`sc1`: straight to this XCD's L2) — for data this CU has just rewritten
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 ld16_sc1(const uint4 *p) {
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void ld16_sc1_x4(const uint4 *const (&p)[4], u32x4 (&v)[4]) {
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
+                 "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]) : "memory");
+}
 
 template <int HT_BITS_, int T_, bool FILTER>
 struct JoinCfg {
@@ -446,8 +460,8 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
             for (uint32_t i = tid; i < Cfg::BM_WORDS / 4; i += T) reinterpret_cast<uint4 *>(s_bm)[i] = make_uint4(0, 0, 0, 0);
             constexpr uint32_t NWV = T / PDL_WAVE;
             const uint32_t wcap = a.defer_cap / NWV;               // every wave files its own part of the list: the count stays in a scalar register
-            unsigned long long *defer = a.defer + (size_t) blockIdx.x * a.defer_cap;
-            unsigned long long *wdefer = defer + (size_t) (tid / PDL_WAVE) * wcap;
+            uint4 *defer = a.defer + (size_t) blockIdx.x * a.defer_cap;
+            uint4 *wdefer = defer + (size_t) (tid / PDL_WAVE) * wcap;
             uint32_t nd_w = 0;
             const uint32_t lane = tid & (PDL_WAVE - 1);
             const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -487,7 +501,7 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
                     for (uint32_t u = 0; u < 4; u++) {
                         if (later[u]) {
                             const uint32_t i = at + (uint32_t) __popcll(m[u] & lt_mask);
-                            if (i < wcap) st_agent(&wdefer[i], (unsigned long long) po[u].x | ((unsigned long long) (0xffffffffu - gsv[u]) << 32));
+                            if (i < wcap) wdefer[i] = make_uint4(po[u].x, 0xffffffffu - gsv[u], p, a.defer_serial);
                         } else if (live[u]) {
                             uint32_t seen;
                             const uint32_t slot = find_or_insert(po[u].x, seen);
@@ -500,38 +514,54 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PH_MARK(9);
 #endif
                 });
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the wave's (write-through) stores to its list are in L2 before it reads them back;
-                                                              // (not __threadfence(): an agent-scope release writes the L2 back — 9x the join's time)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the wave's stores to its list have been acknowledged by L2 before it reads them back
                 __syncthreads();
                 PH_MARK(2);
             }
             if (!s_overflow) {
                 // The lookups put aside: add the ones whose column was kept.  Every wave goes through the part of the list
-                // it wrote itself — nothing here depends on seeing another wave's global stores (an earlier version read all
-                // four parts from every wave and, rarely, found the previous row's entries there: barrier and fence
-                // notwithstanding); the barrier above is for the table, which all waves fill.
+                // it wrote itself — nothing here depends on seeing another wave's global stores; the barrier above is for
+                // the table, which all waves fill.  The list is rewritten row after row, so what a load must not return is
+                // the PREVIOUS content of an entry.  Twice that has happened (first with cross-wave reads behind a fence and
+                // a barrier, then — rarely, and only after an unrelated edit changed the kernel's timing — with a wave
+                // reading back its own `sc1` stores, which leave L2 for the fabric while an `sc1` load that misses L2 can
+                // reach memory before them).  So: plain 16-byte stores (write-through L1, the line STAYS in this XCD's L2),
+                // 16-byte `sc1` loads (never served by L1), and every entry carries the row and the launch it was written
+                // for: an entry that does not is loaded again.  The check makes the result independent of when a store
+                // becomes visible; a load that never sees it gives up and counts an error (the host fails the pass).
                 for (uint32_t i0 = 0; i0 < nd_w; i0 += 4 * PDL_WAVE) {
-                    unsigned long long e[4];
+                    u32x4 e[4];
                     uint32_t slot[4];
                     uint2 kf[4];
                     bool have[4];
-#pragma unroll
-                    for (uint32_t u = 0; u < 4; u++) {       // four loads, then four first probes in flight
-                        const uint32_t i = i0 + u * PDL_WAVE + lane;
-                        have[u] = i < nd_w;
-                        e[u] = ld_agent(&wdefer[have[u] ? i : 0u]);
-                    }
+                    const uint4 *src[4];
 #pragma unroll
                     for (uint32_t u = 0; u < 4; u++) {
-                        slot[u] = ((uint32_t) e[u] * 2654435761u) >> (32 - HT_BITS_);
+                        const uint32_t i = i0 + u * PDL_WAVE + lane;
+                        have[u] = i < nd_w;
+                        src[u] = &wdefer[have[u] ? i : 0u];
+                    }
+                    ld16_sc1_x4(src, e);                     // four loads in flight, one wait
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; u++) {
+                        uint32_t tries = 0;
+                        while (have[u] && (e[u].z != p || e[u].w != a.defer_serial)) {       // not (yet) what this wave stored there for this row
+                            if (tries == 0) atomicAdd(a.reload_count, 1u);
+                            if (++tries > 4096u) { atomicAdd(a.error_count, 1u); have[u] = false; break; }
+                            e[u] = ld16_sc1(src[u]);
+                        }
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; u++) {       // four first probes in flight
+                        slot[u] = (e[u].x * 2654435761u) >> (32 - HT_BITS_);
                         kf[u] = s_kf[slot[u]];
                     }
 #pragma unroll
                     for (uint32_t u = 0; u < 4; u++) {
                         if (!have[u]) continue;
-                        const uint32_t col = (uint32_t) e[u];
+                        const uint32_t col = e[u].x;
                         for (;;) {
-                            if (kf[u].x == col) { add_to(slot[u], kf[u].y, 1u, 1u, (uint32_t) (e[u] >> 32)); break; }
+                            if (kf[u].x == col) { add_to(slot[u], kf[u].y, 1u, 1u, e[u].y); break; }
                             if (kf[u].x == EMPTY_KEY) break;         // column was seen once only
                             slot[u] = (slot[u] + 1) & (HT - 1);
                             kf[u] = s_kf[slot[u]];
@@ -601,7 +631,6 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
                         // use the same integers the row program of c would have summed); K-order places it in c's row.
                         // Multi-GPU: when c is another GPU's row the staged cell travels there (k_outbox_*).
                         const uint32_t pc = ci.z;
-                        a.st_src[o] = r;
                         if (pc != 0xffffffffu) {
                             atomicAdd(&a.mirror_cnt[pc], 1u);
                             atomicMax(reinterpret_cast<uint32_t *>(a.MS + (size_t) pc * a.G + my_genome), __float_as_uint(score));
@@ -747,7 +776,6 @@ __global__ __launch_bounds__(HBM_THREADS) void k_join_hbm(JoinArgs a) {
                 atomicMax(reinterpret_cast<uint32_t *>(cm_row + c), __float_as_uint(score));
                 if (a.mirror) {      // cell (c, r), see k_join_lds
                     const uint32_t pc = a.taskpos_of[c];
-                    a.st_src[o] = r;
                     if (pc != 0xffffffffu) {
                         atomicAdd(&a.mirror_cnt[pc], 1u);
                         atomicMax(reinterpret_cast<uint32_t *>(a.MS + (size_t) pc * a.G + a.genome_of[r]), __float_as_uint(score));
@@ -790,7 +818,7 @@ struct OrderArgs {
     const float *st_score, *st_perc, *st_tr;
     const uint32_t *st_col, *st_first;
     // mirror mode: row p also owns mirror_cnt[p] cells that other rows staged; mcell holds them from mirror_off[p] on
-    const uint32_t *st_src, *mirror_cnt, *mirror_off;
+    const uint32_t *mirror_cnt, *mirror_off;
     const MCell *mcell;
     float *c_score, *c_perc, *c_tr;
     int32_t *c_row, *c_col;
@@ -1013,7 +1041,7 @@ __global__ __launch_bounds__(256) void k_order_rows_wave(OrderArgs a) {
 struct MirrorArgs {
     const uint32_t *row_base, *row_cnt, *task_rows;
     const float *st_score, *st_perc, *st_tr;
-    const uint32_t *st_col, *st_first, *st_src;
+    const uint32_t *st_col, *st_first;
     const uint32_t *taskpos_of, *mirror_off;
     uint32_t *mirror_cur;
     uint32_t n_rows;
@@ -1080,40 +1108,37 @@ __global__ void k_outbox_totals(const uint32_t *offs, uint32_t n_blocks, uint32_
 }
 
 struct InboxArgs {
-    const pdl_dist_cell *in; uint32_t n, slot0;
-    float *st_score, *st_perc, *st_tr;
-    uint32_t *st_col, *st_first, *st_src;
+    const pdl_dist_cell *in; uint32_t n;
     const uint32_t *taskpos_of, *genome_of, *local_genome;
     uint32_t *mirror_cnt;
     float *MS, *CM;
     uint32_t N, G;
     uint32_t *error_count;
 };
-// a received cell (r, c): staged like a local one, counted for row c and folded into c's maxima (library.cpp:513-515
-// seen from row c: its column is r)
+// a received cell (r, c): counted for row c and folded into c's maxima (library.cpp:513-515 seen from row c: its column is
+// r).  It stays where the exchange put it: k_mirror_cells_inbox copies it from there into c's stretch once the stretches
+// are known (it used to be filed in the staging arrays in between: 24 bytes written and read back per cell for nothing).
 __global__ __launch_bounds__(256) void k_inbox_file(InboxArgs a) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= a.n) return;
     const pdl_dist_cell cl = a.in[i];
     if (cl.column >= a.N || cl.row >= a.N) { atomicAdd(a.error_count, 1u); return; }
     const uint32_t pc = a.taskpos_of[cl.column];
-    const uint32_t slot = a.slot0 + i;
-    a.st_score[slot] = cl.score; a.st_perc[slot] = cl.perc; a.st_tr[slot] = cl.tr_perc;
-    a.st_col[slot] = cl.column; a.st_src[slot] = cl.row; a.st_first[slot] = cl.first_group;
     if (pc == 0xffffffffu) { atomicAdd(a.error_count, 1u); return; }      // not a row of this GPU: the exchange went wrong
     atomicAdd(&a.mirror_cnt[pc], 1u);
     atomicMax(reinterpret_cast<uint32_t *>(a.MS + (size_t) pc * a.G + a.genome_of[cl.row]), __float_as_uint(cl.score));
     atomicMax(reinterpret_cast<uint32_t *>(a.CM + (size_t) a.local_genome[a.genome_of[cl.column]] * a.N + cl.row), __float_as_uint(cl.score));
 }
-// ... and the cells received from other GPUs (filed at staging slots slot0 ..: row = the sender's gene, in st_src)
-__global__ __launch_bounds__(256) void k_mirror_cells_inbox(MirrorArgs a, uint32_t slot0, uint32_t n) {
+// ... and the cells received from other GPUs (row = the sender's gene)
+__global__ __launch_bounds__(256) void k_mirror_cells_inbox(MirrorArgs a, const pdl_dist_cell *__restrict__ in, uint32_t n, uint32_t n_genes) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const uint32_t s = slot0 + i;
-    const uint32_t pc = a.taskpos_of[a.st_col[s]];
+    const pdl_dist_cell cl = in[i];
+    if (cl.column >= n_genes || cl.row >= n_genes) return;               // (counted as an error by k_inbox_file)
+    const uint32_t pc = a.taskpos_of[cl.column];
     if (pc == 0xffffffffu) return;
     const uint32_t dst = a.mirror_off[pc] + atomicAdd(&a.mirror_cur[pc], 1u);
-    a.mcell[dst] = MCell{a.st_src[s], a.st_first[s], a.st_score[s], a.st_tr[s], a.st_perc[s], 0u};
+    a.mcell[dst] = MCell{cl.row, cl.first_group, cl.score, cl.tr_perc, cl.perc, 0u};
 }
 
 // work-item descriptors of the LDS join, in processing order (currently task order)
@@ -1165,6 +1190,7 @@ __global__ void k_gather_u32(const uint32_t *src, const uint32_t *idx, uint32_t 
     if (i < n) dst[i] = src[idx[i]];
     else if (i < n + 8) dst[i] = ctr[i - n];
     else if (i < n + 10) dst[i] = z64[i - n - 8];
+    else if (i == n + 10) dst[i] = ctr[10];          // entries of the put-aside lists that had to be loaded again
 }
 
 // Clears up to four arrays in one launch (16-byte words; every separate small fill is a dispatch of its own).
@@ -1326,15 +1352,16 @@ static void score_alloc_rows(pdl_ctx *c, const ScorePlan &pl) {
                        N, c->gene_info.as<uint4>());
 }
 
-// staging for `cap` cells of this context's rows + `extra` cells received from other GPUs (slots cap .. cap + extra)
-static void score_alloc_cells(pdl_ctx *c, const ScorePlan &pl, unsigned long long cap, unsigned long long extra, bool keep) {
-    const unsigned long long st_total = cap + extra;
+// staging for `cap` cells of this context's rows; final cells and mirrored copies also for `extra` cells received from other
+// GPUs (those stay in the caller's exchange buffer until they are copied into their rows' stretches).  Growing `extra` after
+// the join leaves the staged cells alone: the staging arrays already have their size.
+static void score_alloc_cells(pdl_ctx *c, const ScorePlan &pl, unsigned long long cap, unsigned long long extra) {
     const unsigned long long fcap = pl.mirror ? 2 * cap + extra : cap;          // final cells: staged ones + their mirrors + received ones
     if (fcap >= 0xffffffffull) PDL_FAIL(PDL_ERR_UNSUPPORTED, "more than 2^32 emitted cells on one device: shard the genomes over more devices");
-    DevBuf *st[6] = {&c->st_score, &c->st_perc, &c->st_tr, &c->st_col, &c->st_first, &c->st_src};
-    for (int i = 0; i < (pl.mirror ? 6 : 5); i++) { if (keep) st[i]->grow_keep(st_total * 4, c->stream); else st[i]->alloc(st_total * 4); }
+    DevBuf *st[5] = {&c->st_score, &c->st_perc, &c->st_tr, &c->st_col, &c->st_first};
+    for (int i = 0; i < 5; i++) st[i]->alloc(cap * 4);
     c->c_score.alloc(fcap * 4); c->c_perc.alloc(fcap * 4); c->c_tr.alloc(fcap * 4); c->c_row.alloc(fcap * 4); c->c_col.alloc(fcap * 4);
-    if (pl.mirror) c->mirror_ref.alloc(st_total * sizeof(MCell));     // the mirrored cells, copied (one per staged / received cell)
+    if (pl.mirror) c->mirror_ref.alloc((cap + extra) * sizeof(MCell));     // the mirrored cells, copied (one per staged / received cell)
     c->st_cap = cap;
 }
 
@@ -1351,7 +1378,7 @@ static JoinArgs join_args(pdl_ctx *c, const ScorePlan &pl) {
     a.st_col = c->st_col.as<uint32_t>(); a.st_first = c->st_first.as<uint32_t>(); a.st_cap = c->st_cap;
     a.mirror = pl.mirror ? 1u : 0u;
     if (pl.mirror) {
-        a.st_src = c->st_src.as<uint32_t>(); a.taskpos_of = c->taskpos_of.as<uint32_t>(); a.local_genome = c->local_genome.as<uint32_t>();
+        a.taskpos_of = c->taskpos_of.as<uint32_t>(); a.local_genome = c->local_genome.as<uint32_t>();
         a.mirror_cnt = c->mirror_cnt.as<uint32_t>();
     }
     return a;
@@ -1377,7 +1404,7 @@ static void score_join(pdl_ctx *c, const ScorePlan &pl) {
     // counters: 0 cursor tier 1 | 1 rows for tier 2 | 2 cursor tier 2 | 3 rows for tier 3 | 4-5 cell cursor | 6 errors | 7 cursor tier 3 | 9 wide rows seen by K-order
     uint32_t *ctr32 = c->join_ctr.as<uint32_t>();
     uint32_t *list_a = c->overflow_rows.as<uint32_t>(), *list_b = list_a + n_rows;
-    a.error_count = ctr32 + 6;
+    a.error_count = ctr32 + 6; a.reload_count = ctr32 + 10;
     a.cell_cursor = reinterpret_cast<unsigned long long *>(ctr32 + 4);
 
     ev_begin(c, EV_JOIN);
@@ -1390,13 +1417,15 @@ static void score_join(pdl_ctx *c, const ScorePlan &pl) {
     a.work_cursor = ctr32 + 0; a.overflow_count = ctr32 + 1; a.overflow_rows = list_a;
     a.work_batch = std::max<uint32_t>(1, std::min<uint32_t>(8, n_rows / (std::max<uint32_t>(pl.grid1, 1) * 8)));
     if (tier1 >= 9 && tier1 <= 11) {
-        // the filter tiers put a row's first sightings aside in a list per workgroup (8 bytes each; rewritten row after row, so
+        // the filter tiers put a row's first sightings aside in a list per workgroup (16 bytes each; rewritten row after row, so
         // only the part in use is ever hot): room for 4x the lookups of the average row (never more than one per gene), a
         // row with more first sightings goes to tier 2
         const unsigned long long avg = n_rows ? c->P / n_rows : 0;
         a.defer_cap = (uint32_t) std::min<unsigned long long>(std::min<unsigned long long>(std::max<unsigned long long>(4 * avg, 8192), 1u << 18), (unsigned long long) N + 64);
-        c->join_defer.alloc((size_t) pl.grid1 * a.defer_cap * sizeof(unsigned long long));
-        a.defer = c->join_defer.as<unsigned long long>();
+        c->join_defer.alloc((size_t) pl.grid1 * a.defer_cap * sizeof(uint4));
+        a.defer = c->join_defer.as<uint4>();
+        static std::atomic<uint32_t> launch_serial{0};        // (process-wide: a freed list may come back to another context as it was left)
+        a.defer_serial = ++launch_serial;
     }
 #ifdef PDL_JOIN_PHASES
     static unsigned long long *d_phase = nullptr;
@@ -1449,7 +1478,7 @@ static void score_join(pdl_ctx *c, const ScorePlan &pl) {
 
 // K-order over the staged cells (+ the n_inbox cells filed at slots st_cap ..), then the one look at the counters.
 // Returns the staging cells the join asked for (> st_cap: the pass must be repeated).
-static unsigned long long score_order(pdl_ctx *c, const ScorePlan &pl, uint32_t n_inbox, int ev_total) {
+static unsigned long long score_order(pdl_ctx *c, const ScorePlan &pl, const pdl_dist_cell *d_inbox, uint32_t n_inbox, int ev_total) {
     hipStream_t st = c->stream;
     const uint32_t n_rows = c->n_task_rows;
     const uint32_t S = (uint32_t) c->shard.size();
@@ -1467,12 +1496,12 @@ static unsigned long long score_order(pdl_ctx *c, const ScorePlan &pl, uint32_t 
         MirrorArgs ma{};
         ma.row_base = c->row_base.as<uint32_t>(); ma.row_cnt = c->row_cnt.as<uint32_t>(); ma.task_rows = c->task_rows.as<uint32_t>();
         ma.st_score = c->st_score.as<float>(); ma.st_perc = c->st_perc.as<float>(); ma.st_tr = c->st_tr.as<float>();
-        ma.st_col = c->st_col.as<uint32_t>(); ma.st_first = c->st_first.as<uint32_t>(); ma.st_src = c->st_src.as<uint32_t>();
+        ma.st_col = c->st_col.as<uint32_t>(); ma.st_first = c->st_first.as<uint32_t>();
         ma.taskpos_of = c->taskpos_of.as<uint32_t>(); ma.mirror_off = m_off; ma.mirror_cur = m_cur; ma.n_rows = n_rows;
         ma.mcell = c->mirror_ref.as<MCell>();
         hipLaunchKernelGGL(k_mirror_cells, dim3((n_rows + 3) / 4), dim3(256), 0, st, ma);
-        if (n_inbox) hipLaunchKernelGGL(k_mirror_cells_inbox, dim3((n_inbox + 255) / 256), dim3(256), 0, st, ma, (uint32_t) c->st_cap, n_inbox);
-        o.st_src = c->st_src.as<uint32_t>(); o.mirror_cnt = d_mcnt; o.mirror_off = m_off; o.mcell = c->mirror_ref.as<MCell>();
+        if (n_inbox) hipLaunchKernelGGL(k_mirror_cells_inbox, dim3((n_inbox + 255) / 256), dim3(256), 0, st, ma, d_inbox, n_inbox, c->N);
+        o.mirror_cnt = d_mcnt; o.mirror_off = m_off; o.mcell = c->mirror_ref.as<MCell>();
     }
     o.row_base = c->row_base.as<uint32_t>(); o.row_cnt = c->row_cnt.as<uint32_t>(); o.fin_off = c->fin_off.as<uint32_t>();
     o.task_rows = c->task_rows.as<uint32_t>();
@@ -1490,19 +1519,20 @@ static unsigned long long score_order(pdl_ctx *c, const ScorePlan &pl, uint32_t 
     // first cell of every shard genome = fin_off at its first task row; then the one look at the counters
     uint32_t *d_idx = c->task_off.as<uint32_t>();
     uint32_t *d_out = d_idx + (S + 1);
-    hipLaunchKernelGGL(k_gather_u32, dim3((S + 1 + 10 + 255) / 256), dim3(256), 0, st, c->fin_off.as<uint32_t>(), d_idx, S + 1, d_out,
+    hipLaunchKernelGGL(k_gather_u32, dim3((S + 1 + 11 + 255) / 256), dim3(256), 0, st, c->fin_off.as<uint32_t>(), d_idx, S + 1, d_out,
                        c->join_ctr.as<uint32_t>(), reinterpret_cast<const uint32_t *>(d_scal + 6));
     c->h_fin.resize(S + 1);
     uint32_t h_ctr[8];
     uint64_t zsum = 0;
     {
         PinRead rd(c);
-        const uint32_t *pf = rd.add<uint32_t>(d_out, S + 1 + 10);
+        const uint32_t *pf = rd.add<uint32_t>(d_out, S + 1 + 11);
         ev_end(c, ev_total);
         rd.sync();
         memcpy(c->h_fin.data(), pf, (size_t) (S + 1) * 4);
         memcpy(h_ctr, pf + S + 1, sizeof(h_ctr));
         memcpy(&zsum, pf + S + 1 + 8, sizeof(zsum));
+        c->tm.aside_reloads = pf[S + 1 + 10];
     }
     c->glb_clean = true;
     c->tm.overflow_rows = h_ctr[3];
@@ -1547,9 +1577,9 @@ void pdl_run_score_all(pdl_ctx *c) {
     score_alloc_rows(c, pl);
     unsigned long long cap = first_staging_cap(c, pl, c->P);
     for (int attempt = 0; attempt < 2; attempt++) {
-        score_alloc_cells(c, pl, cap, 0, false);
+        score_alloc_cells(c, pl, cap, 0);
         score_join(c, pl);
-        const unsigned long long z = score_order(c, pl, 0, EV_SCORE_TOTAL);
+        const unsigned long long z = score_order(c, pl, nullptr, 0, EV_SCORE_TOTAL);
         if (z <= cap) break;
         if (attempt == 1) PDL_FAIL(PDL_ERR_DEVICE, "staging overflow persisted (%llu cells > %llu)", z, cap);
         cap = z + pl.slack;      // what was asked for plus chunk slack, second and last attempt
@@ -1590,7 +1620,7 @@ void pdl_run_dist_score_begin(pdl_ctx *c) {
     unsigned long long cap = first_staging_cap(c, pl, std::max<uint64_t>(upper, 1));
     for (int attempt = 0; attempt < 2; attempt++) {
         // room for as many received cells as staged ones right away (the exchange is symmetric on average); grown if short
-        score_alloc_cells(c, pl, cap, cap, false);
+        score_alloc_cells(c, pl, cap, cap);
         score_join(c, pl);
         OutboxArgs oa{};
         oa.row_base = c->row_base.as<uint32_t>(); oa.row_cnt = c->row_cnt.as<uint32_t>(); oa.task_rows = c->task_rows.as<uint32_t>();
@@ -1651,20 +1681,18 @@ void pdl_run_dist_score_finish(pdl_ctx *c, const pdl_dist_cell *d_inbox, uint64_
     }
     const ScorePlan pl = score_plan(c);
     const unsigned long long cap = c->st_cap;
-    if (n_inbox > cap) score_alloc_cells(c, pl, cap, n_inbox, true);       // (rare: the first allocation leaves room for `cap` received cells)
+    if (n_inbox > cap) score_alloc_cells(c, pl, cap, n_inbox);             // (rare: the first allocation leaves room for `cap` received cells)
     else if (2 * cap + n_inbox >= 0xffffffffull) PDL_FAIL(PDL_ERR_UNSUPPORTED, "more than 2^32 emitted cells on one device");
     if (n_inbox) {
         InboxArgs ia{};
-        ia.in = d_inbox; ia.n = (uint32_t) n_inbox; ia.slot0 = (uint32_t) cap;
-        ia.st_score = c->st_score.as<float>(); ia.st_perc = c->st_perc.as<float>(); ia.st_tr = c->st_tr.as<float>();
-        ia.st_col = c->st_col.as<uint32_t>(); ia.st_first = c->st_first.as<uint32_t>(); ia.st_src = c->st_src.as<uint32_t>();
+        ia.in = d_inbox; ia.n = (uint32_t) n_inbox;
         ia.taskpos_of = c->taskpos_of.as<uint32_t>(); ia.genome_of = c->d_gen; ia.local_genome = c->local_genome.as<uint32_t>();
         ia.mirror_cnt = c->mirror_cnt.as<uint32_t>(); ia.MS = c->MS.as<float>(); ia.CM = c->CM.as<float>();
         ia.N = c->N; ia.G = c->G; ia.error_count = c->join_ctr.as<uint32_t>() + 6;
         hipLaunchKernelGGL(k_inbox_file, dim3((uint32_t) ((n_inbox + 255) / 256)), dim3(256), 0, st, ia);
         PDL_HIP(hipGetLastError());
     }
-    const unsigned long long z = score_order(c, pl, (uint32_t) n_inbox, EV_DIST_SCORE_FINISH);
+    const unsigned long long z = score_order(c, pl, d_inbox, (uint32_t) n_inbox, EV_DIST_SCORE_FINISH);
     if (z > cap) PDL_FAIL(PDL_ERR_DEVICE, "staging cursor moved after the join (%llu > %llu)", z, cap);
     c->tm.order_ms = ev_ms(c, EV_ORDER);
     c->tm.dist_score_finish_ms = ev_ms(c, EV_DIST_SCORE_FINISH);

@@ -75,7 +75,12 @@ def test_repeated_scoring_reproduces_the_digest_every_time():
     """A regression test for a race that showed as a few extra cells in one run out of six: the join's list of lookups
     put aside (first sightings) was read back by other waves than the ones that wrote it, and — rarely, depending on how
     the kernel happened to be scheduled — a wave found the previous row's entries there.  The near-identical genomes of
-    this set (a row's neighbour is the homolog of its homolog's neighbour) turn one stale entry into a wrong cell."""
+    this set (a row's neighbour is the homolog of its homolog's neighbour) turn one stale entry into a wrong cell.
+    It came back once more, with every wave reading only its own entries, when an unrelated edit changed the kernel's timing
+    again (+1 to +3 cells in two passes out of four): the entries were stored `sc1`, which sends the line out of L2, and an
+    `sc1` load behind them could reach memory first.  Now the stores are plain (the line stays in the XCD's L2), the loads
+    `sc1`, and every entry names the row and the launch it was written for — one that does not is loaded again
+    (pdl_timings.aside_reloads counts those: 0 in every run so far)."""
     from pandelos_amd.pangene_native import PangeneNative
     name = "salmonella7_standin"
     d = BASE[name]

@@ -143,11 +143,10 @@ __device__ __forceinline__ float finalize_cell(unsigned long long acc, uint32_t 
 // Rows whose keys do not fit are appended to an overflow list for the next tier.
 // ------------------------------------------------------------------------------------------------
 
-// loads / stores that go to L2 (agent scope): tables and lists in HBM that a workgroup writes and reads back
+// loads served by L2, never by L1 (agent scope = `sc1`): tables and lists in HBM that a workgroup writes (plain stores or
+// L2 atomics) and reads back
 __device__ __forceinline__ uint32_t ld_agent(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // 16-byte loads that L1 never serves (`sc1`: straight to this XCD's L2) — for data this CU has just rewritten
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -659,9 +658,12 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
 }
 
 // ------------------------------------------------------------------------------------------------
-// K-join (HBM tables): direct-addressed by column id, private to the workgroup; every access to the
-// tables is an L2-level atomic or an agent-scope (L1-bypassing) load/store, so the workgroup sees
-// its own updates without fences.  Tables are all-zero between rows.
+// K-join (HBM tables): direct-addressed by column id, private to the workgroup (one CU, one XCD, one L2).  Every update of
+// the tables is an L2-level atomic or a PLAIN store (write-through L1, the line stays in that L2), every read an `sc1`
+// load (never served by L1), and a storing wave waits for its stores (vmcnt) before the barrier that hands them over: the
+// workgroup sees its own updates in L2.  No `sc1` STORES: they send the line out of L2 to the fabric, and a load or an
+// atomic that then misses L2 can reach memory before them (seen in the LDS tier's put-aside list).  Tables are all-zero
+// between rows.
 // ------------------------------------------------------------------------------------------------
 
 // WIDE = true keeps the three sums in separate 32-bit counters (the reference's int arrays, library.cpp:421-423) instead of
@@ -737,6 +739,7 @@ __global__ __launch_bounds__(HBM_THREADS) void k_join_hbm(JoinArgs a) {
             }
         }
         __threadfence();      // the touched list was written with plain stores by other waves of this workgroup
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const uint32_t ntouched = min(s_ntouched, a.N);
         const uint32_t my_kcnt = a.kseq_len[r];
@@ -747,9 +750,10 @@ __global__ __launch_bounds__(HBM_THREADS) void k_join_hbm(JoinArgs a) {
             const float score = read_cell(c, my_kcnt, threshold, perc, tr);
             if (score > 0.0f) {
                 const uint32_t idx = atomicAdd(&s_nemit, 1u);
-                if (idx < a.N) st_agent(&t_emit[idx], c);
+                if (idx < a.N) t_emit[idx] = c;
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (a barrier does not wait for stores)
         __syncthreads();
         const uint32_t nemit = min(s_nemit, a.N);
         if (tid == 0) {
@@ -788,13 +792,14 @@ __global__ __launch_bounds__(HBM_THREADS) void k_join_hbm(JoinArgs a) {
         for (uint32_t t = tid; t < ntouched; t += JOIN_THREADS) {
             const uint32_t c = ld_agent(&t_touched[t]);
             if (c < a.N) {
-                if constexpr (WIDE) { st_agent(&t_w[c], 0u); st_agent(&t_w[a.N + c], 0u); st_agent(&t_w[2 * (size_t) a.N + c], 0u); }
-                else st_agent(&t_acc[c], 0ull);
-                st_agent(&t_first[c], 0u);
+                if constexpr (WIDE) { t_w[c] = 0u; t_w[a.N + c] = 0u; t_w[2 * (size_t) a.N + c] = 0u; }
+                else t_acc[c] = 0ull;
+                t_first[c] = 0u;
             }
         }
         if (tid == 0) { s_ntouched = 0; s_nemit = 0; }
-        __threadfence();      // the zeroing stores must have landed before the next row's atomics
+        __threadfence();      // the zeroing stores must have landed (in L2) before the next row's atomics
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 }

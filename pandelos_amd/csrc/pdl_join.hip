@@ -74,7 +74,9 @@ struct JoinArgs {
 #ifdef PDL_JOIN_PHASES
     unsigned long long *phase;     // diagnostic build (-DPDL_JOIN_PHASES): time the first thread of every workgroup spends in the phases of a row (100-MHz ticks, summed)
 #endif
-    uint4 *defer;                  // filter tiers: per workgroup, the first light sightings of the row in hand {column, 0xffffffff - group key, row, launch}
+    void *defer;                   // filter tiers: per workgroup, the first light sightings of the row in hand: {column | tag << 22, 0xffffffff - group key}
+                                   // (8 bytes, gene ids below 2^22) or {column, 0xffffffff - group key, row, launch} (16 bytes), see defer_wide
+    uint32_t defer_wide;
     uint32_t defer_cap;            // entries per workgroup; a row with more goes to the next tier
     uint32_t *reload_count;        // entries that were not there at the first look (diagnostic, pdl_timings.aside_reloads)
     uint32_t defer_serial;         // this launch's number: with the row it makes an entry recognisable as written for THIS row
@@ -177,7 +179,7 @@ struct JoinCfg {
 };
 
 template <int HT_BITS_, int T_, bool FILTER>
-__global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join_lds(JoinArgs a) {
+__global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : (FILTER && T_ == 256) ? 3 : 1) void k_join_lds(JoinArgs a) {
     using Cfg = JoinCfg<HT_BITS_, T_, FILTER>;
     constexpr uint32_t HT = Cfg::HT, LIMIT = Cfg::LIMIT, TOUCH_CAP = Cfg::TOUCH_CAP, RB = Cfg::RB, RPT = Cfg::RPT;
     constexpr int T = T_;
@@ -459,8 +461,12 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
             for (uint32_t i = tid; i < Cfg::BM_WORDS / 4; i += T) reinterpret_cast<uint4 *>(s_bm)[i] = make_uint4(0, 0, 0, 0);
             constexpr uint32_t NWV = T / PDL_WAVE;
             const uint32_t wcap = a.defer_cap / NWV;               // every wave files its own part of the list: the count stays in a scalar register
-            uint4 *defer = a.defer + (size_t) blockIdx.x * a.defer_cap;
-            uint4 *wdefer = defer + (size_t) (tid / PDL_WAVE) * wcap;
+            // entry of the list: 8 bytes {column | 10-bit tag << 22, group} when gene ids fit 22 bits, else 16 {column, group, row, launch}
+            const bool wide_list = a.defer_wide != 0;
+            const size_t wlist0 = (size_t) blockIdx.x * a.defer_cap + (size_t) (tid / PDL_WAVE) * wcap;
+            uint4 *wdefer16 = reinterpret_cast<uint4 *>(a.defer) + wlist0;
+            uint2 *wdefer8 = reinterpret_cast<uint2 *>(a.defer) + wlist0;
+            const uint32_t tag10 = ((p + 389u * a.defer_serial) & 1023u) << 22;
             uint32_t nd_w = 0;
             const uint32_t lane = tid & (PDL_WAVE - 1);
             const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -500,7 +506,10 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
                     for (uint32_t u = 0; u < 4; u++) {
                         if (later[u]) {
                             const uint32_t i = at + (uint32_t) __popcll(m[u] & lt_mask);
-                            if (i < wcap) wdefer[i] = make_uint4(po[u].x, 0xffffffffu - gsv[u], p, a.defer_serial);
+                            if (i < wcap) {
+                                if (wide_list) wdefer16[i] = make_uint4(po[u].x, 0xffffffffu - gsv[u], p, a.defer_serial);
+                                else wdefer8[i] = make_uint2(po[u].x | tag10, 0xffffffffu - gsv[u]);
+                            }
                         } else if (live[u]) {
                             uint32_t seen;
                             const uint32_t slot = find_or_insert(po[u].x, seen);
@@ -524,43 +533,64 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : 1) void k_join
                 // the PREVIOUS content of an entry.  Twice that has happened (first with cross-wave reads behind a fence and
                 // a barrier, then — rarely, and only after an unrelated edit changed the kernel's timing — with a wave
                 // reading back its own `sc1` stores, which leave L2 for the fabric while an `sc1` load that misses L2 can
-                // reach memory before them).  So: plain 16-byte stores (write-through L1, the line STAYS in this XCD's L2),
-                // 16-byte `sc1` loads (never served by L1), and every entry carries the row and the launch it was written
-                // for: an entry that does not is loaded again.  The check makes the result independent of when a store
-                // becomes visible; a load that never sees it gives up and counts an error (the host fails the pass).
+                // reach memory before them).  So: plain stores (write-through L1, the line STAYS in this XCD's L2), `sc1` loads
+                // (never served by L1, so L2 it is) — a wave's own stores, acknowledged by L2, then its own loads from L2 —
+                // and every entry carries a tag of the row (and launch) it was written for: one that does not show it is
+                // loaded again, and counted (pdl_timings.aside_reloads — the canary: 0 in every run so far).  16-byte entries
+                // carry row and launch in full; the 8-byte ones (gene ids below 2^22: every BASELINE set) have room for
+                // ten bits, which tell a previous row's entry 1023 times in 1024 — enough for the canary to go off long
+                // before a stale entry could pass, and configs[4]'s join pays 36 % for the other eight bytes.  A load that
+                // never shows the tag gives up and counts an error (the host fails the pass).
                 for (uint32_t i0 = 0; i0 < nd_w; i0 += 4 * PDL_WAVE) {
-                    u32x4 e[4];
-                    uint32_t slot[4];
+                    uint32_t col[4], grp[4], slot[4];
                     uint2 kf[4];
                     bool have[4];
-                    const uint4 *src[4];
+                    uint32_t at[4];
 #pragma unroll
                     for (uint32_t u = 0; u < 4; u++) {
                         const uint32_t i = i0 + u * PDL_WAVE + lane;
                         have[u] = i < nd_w;
-                        src[u] = &wdefer[have[u] ? i : 0u];
+                        at[u] = have[u] ? i : 0u;
                     }
-                    ld16_sc1_x4(src, e);                     // four loads in flight, one wait
+                    if (wide_list) {                             // (uniform)
+                        u32x4 e[4];
+                        const uint4 *src[4] = {&wdefer16[at[0]], &wdefer16[at[1]], &wdefer16[at[2]], &wdefer16[at[3]]};
+                        ld16_sc1_x4(src, e);                     // four loads in flight, one wait
 #pragma unroll
-                    for (uint32_t u = 0; u < 4; u++) {
-                        uint32_t tries = 0;
-                        while (have[u] && (e[u].z != p || e[u].w != a.defer_serial)) {       // not (yet) what this wave stored there for this row
-                            if (tries == 0) atomicAdd(a.reload_count, 1u);
-                            if (++tries > 4096u) { atomicAdd(a.error_count, 1u); have[u] = false; break; }
-                            e[u] = ld16_sc1(src[u]);
+                        for (uint32_t u = 0; u < 4; u++) {
+                            uint32_t tries = 0;
+                            while (have[u] && (e[u].z != p || e[u].w != a.defer_serial)) {   // not (yet) what this wave stored there for this row
+                                if (tries == 0) atomicAdd(a.reload_count, 1u);
+                                if (++tries > 4096u) { atomicAdd(a.error_count, 1u); have[u] = false; break; }
+                                e[u] = ld16_sc1(src[u]);
+                            }
+                            col[u] = e[u].x; grp[u] = e[u].y;
+                        }
+                    } else {
+                        unsigned long long e[4];
+#pragma unroll
+                        for (uint32_t u = 0; u < 4; u++) e[u] = ld_agent(reinterpret_cast<const unsigned long long *>(&wdefer8[at[u]]));
+#pragma unroll
+                        for (uint32_t u = 0; u < 4; u++) {
+                            uint32_t tries = 0;
+                            while (have[u] && ((uint32_t) e[u] & 0xffc00000u) != tag10) {
+                                if (tries == 0) atomicAdd(a.reload_count, 1u);
+                                if (++tries > 4096u) { atomicAdd(a.error_count, 1u); have[u] = false; break; }
+                                e[u] = ld_agent(reinterpret_cast<const unsigned long long *>(&wdefer8[at[u]]));
+                            }
+                            col[u] = (uint32_t) e[u] & 0x3fffffu; grp[u] = (uint32_t) (e[u] >> 32);
                         }
                     }
 #pragma unroll
                     for (uint32_t u = 0; u < 4; u++) {       // four first probes in flight
-                        slot[u] = (e[u].x * 2654435761u) >> (32 - HT_BITS_);
+                        slot[u] = (col[u] * 2654435761u) >> (32 - HT_BITS_);
                         kf[u] = s_kf[slot[u]];
                     }
 #pragma unroll
                     for (uint32_t u = 0; u < 4; u++) {
                         if (!have[u]) continue;
-                        const uint32_t col = e[u].x;
                         for (;;) {
-                            if (kf[u].x == col) { add_to(slot[u], kf[u].y, 1u, 1u, e[u].y); break; }
+                            if (kf[u].x == col[u]) { add_to(slot[u], kf[u].y, 1u, 1u, grp[u]); break; }
                             if (kf[u].x == EMPTY_KEY) break;         // column was seen once only
                             slot[u] = (slot[u] + 1) & (HT - 1);
                             kf[u] = s_kf[slot[u]];
@@ -1427,8 +1457,9 @@ static void score_join(pdl_ctx *c, const ScorePlan &pl) {
         // row with more first sightings goes to tier 2
         const unsigned long long avg = n_rows ? c->P / n_rows : 0;
         a.defer_cap = (uint32_t) std::min<unsigned long long>(std::min<unsigned long long>(std::max<unsigned long long>(4 * avg, 8192), 1u << 18), (unsigned long long) N + 64);
-        c->join_defer.alloc((size_t) pl.grid1 * a.defer_cap * sizeof(uint4));
-        a.defer = c->join_defer.as<uint4>();
+        a.defer_wide = N >= (1u << 22) ? 1u : 0u;
+        c->join_defer.alloc((size_t) pl.grid1 * a.defer_cap * (a.defer_wide ? sizeof(uint4) : sizeof(uint2)));
+        a.defer = c->join_defer.p;
         static std::atomic<uint32_t> launch_serial{0};        // (process-wide: a freed list may come back to another context as it was left)
         a.defer_serial = ++launch_serial;
     }

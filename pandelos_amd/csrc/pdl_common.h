@@ -19,6 +19,20 @@
 
 #define PDL_WAVE 64
 
+// The workgroup barrier of every kernel here: all LDS operations of the wave have COMPLETED before it arrives.
+// hipcc (ROCm 7.2, gfx950) leaves the `s_waitcnt lgkmcnt(0)` out in front of an `s_barrier` when the wave needs no LDS result
+// any more — e.g. behind a run of no-return LDS atomics or stores — relying on the LDS pipe serving the CU's waves in order.
+// On MI355X that does not hold across waves: with two or three 53-KB workgroups per CU the 2048-slot join tier read staged
+// ranges and table slots of the row BEFORE (the wave in front of the barrier still had writes queued), a few wrong cells per
+// pass on the last genomes of a 16-genome set, 0 with this wait in place.  The wait costs nothing
+// when nothing is outstanding.
+#ifdef __HIPCC__
+__device__ __forceinline__ void pdl_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+#endif
+
 // layout of the control block (pdl_ctx::scalars, u64 words): scalars | residue histogram | per-genome cost
 constexpr size_t PDL_CTL_HIST = 16, PDL_CTL_GCOST = 16 + 256;
 
@@ -270,13 +284,13 @@ struct PinReadArgs {
 static __global__ __launch_bounds__(256) void k_pin_read(PinReadArgs a) {
     __shared__ uint32_t s_sum;
     if (threadIdx.x == 0) s_sum = 0;
-    __syncthreads();
+    pdl_sync();
     uint32_t sum = 0;
     for (uint32_t s = 0; s < a.n; s++)
         for (uint32_t i = threadIdx.x; i < a.words[s]; i += 256) { const uint32_t v = a.src[s][i]; a.pin[a.dst_word[s] + i] = v; sum += v * (2u * i + 1u); }
     atomicAdd(&s_sum, sum);
     __threadfence_system();
-    __syncthreads();
+    pdl_sync();
     // The flag says "all of it has been sent", the checksum beside it lets the host see that all of it has ARRIVED: the
     // words travel from several waves over several paths, and the flag may overtake the last of them.
     if (threadIdx.x == 0) {

@@ -42,7 +42,7 @@ constexpr int HIST_THREADS = 256;
 __global__ __launch_bounds__(HIST_THREADS) void k_hist(const uint8_t *__restrict__ res, uint64_t n, unsigned long long *__restrict__ hist) {
     __shared__ uint32_t s_seen[256];
     s_seen[threadIdx.x] = 0;
-    __syncthreads();
+    pdl_sync();
     const uint64_t n16 = n / 16;
     const uint4 *res16 = reinterpret_cast<const uint4 *>(res);
     const uint64_t stride = (uint64_t) gridDim.x * HIST_THREADS;
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(HIST_THREADS) void k_hist(const uint8_t *__restrict
     for (; i < n16; i += stride) mark(res16[i]);
     if (blockIdx.x == 0)    // tail bytes
         for (uint64_t t = n16 * 16 + threadIdx.x; t < n; t += HIST_THREADS) s_seen[res[t]] = 1u;
-    __syncthreads();
+    pdl_sync();
     if (s_seen[threadIdx.x]) hist[threadIdx.x] = 1ull;
 }
 
@@ -171,12 +171,12 @@ __global__ __launch_bounds__(RANK_THREADS) void k_rank(const uint8_t *__restrict
     if constexpr (MODE == 1) for (uint32_t i = threadIdx.x; i < DIST_BINS; i += RANK_THREADS) s_bins[i] = 0;
     const uint64_t tiles = (m + RANK_TILE - 1) / RANK_TILE;
   for (uint64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {      // MODE 0: grid = tiles, one trip
-    __syncthreads();                                            // (the staged boundaries of the previous tile are done with)
+    pdl_sync();                                            // (the staged boundaries of the previous tile are done with)
     const uint64_t q0 = tile * RANK_TILE;
     const uint64_t q_last = min(q0 + RANK_TILE, m) - 1;
     if (threadIdx.x == 0) s_lo = upper_bound_u64(kmer_off, 0, n_seq + 1, q0) - 1;
     if (threadIdx.x == 64) s_hi = upper_bound_u64(kmer_off, 0, n_seq + 1, q_last) - 1;
-    __syncthreads();
+    pdl_sync();
     const uint32_t lo = s_lo, hi = s_hi;
     const uint32_t span = hi - lo + 1;                          // genes under this tile (uniform)
     const bool staged = span <= RANK_SPAN;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(RANK_THREADS) void k_rank(const uint8_t *__restrict
         for (uint32_t i = threadIdx.x; i <= span; i += RANK_THREADS) s_koff[i] = kmer_off[lo + i];
         for (uint32_t i = threadIdx.x; i < span; i += RANK_THREADS) s_off[i] = off[lo + i];
     }
-    __syncthreads();
+    pdl_sync();
     const uint32_t k = rp.k;
     const KeyT base = (KeyT) rp.base;                           // the polynomial fits KeyT (checked on the host): KeyT arithmetic
     // Phase 1: gene and residue position of the lane's four k-mers.  Phase 2: their residues, eight bytes per load, the
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(RANK_THREADS) void k_rank(const uint8_t *__restrict
     }
   }
     if constexpr (MODE == 1) {
-        __syncthreads();
+        pdl_sync();
         for (uint32_t i = threadIdx.x; i < DIST_BINS; i += RANK_THREADS) { const uint32_t v = s_bins[i]; if (v) atomicAdd(&bins[i], v); }
     }
 }
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void k_rank_hash(const uint8_t *__restrict__ r
                                                    uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t *__restrict__ bins) {
     __shared__ uint8_t s_rv[256];
     for (int i = threadIdx.x; i < 256; i += 256) s_rv[i] = rp.rank_values[i];
-    __syncthreads();
+    pdl_sync();
     const uint32_t s = blockIdx.x * 256 + threadIdx.x;
     if (s >= n_seq) return;
     const uint64_t b = off[s], e = off[s + 1];
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(1024) void k_fold_last_record(uint2 *__restrict__ p
             s_gs = gs; s_p = lo;
         }
     }
-    __syncthreads();
+    pdl_sync();
     const uint32_t p = s_p, gs = s_gs;
     if (p == lastp) { if (threadIdx.x == 0) post[lastp] = last; return; }       // already in place (uniform)
     for (uint32_t hi = lastp; hi > p; hi = hi > 1024 ? hi - 1024 : 0) {
@@ -424,9 +424,9 @@ __global__ __launch_bounds__(1024) void k_fold_last_record(uint2 *__restrict__ p
         uint2 v = make_uint2(0, 0);
         uint32_t rp = 0;
         if (live) { v = post[i]; if (recpos) rp = recpos[i]; }
-        __syncthreads();
+        pdl_sync();
         if (live) { post[i + 1] = v; if (recpos) recpos[i + 1] = rp; }
-        __syncthreads();
+        pdl_sync();
         if (hi <= 1024) break;
     }
     if (threadIdx.x == 0) {
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(GW_THREADS) void k_group_waves(GroupTileArgs a) {
     const bool lds_table = GENOMES && a.n_genomes <= COST_LDS_GENOMES;
     if constexpr (GENOMES) { if (lds_table) { for (uint32_t i = tid; i < 2 * a.n_genomes; i += GW_THREADS) s_dyn[i] = 0; } }
     if (tid < 2) s_red[tid] = 0;
-    __syncthreads();
+    pdl_sync();
     const unsigned long long lt_mask = (1ull << lane) - 1ull, le_mask = (2ull << lane) - 1ull;
     uint32_t n_rec = 0, n_grp = 0;
     unsigned long long own_lookups = 0;
@@ -640,7 +640,7 @@ __global__ __launch_bounds__(GW_THREADS) void k_group_waves(GroupTileArgs a) {
 #pragma unroll
         for (int d = PDL_WAVE / 2; d > 0; d >>= 1) { n_rec += __shfl_xor(n_rec, d, PDL_WAVE); n_grp += __shfl_xor(n_grp, d, PDL_WAVE); }
         if (lane == 0) { atomicAdd(&s_red[0], n_rec); atomicAdd(&s_red[1], n_grp); }
-        __syncthreads();
+        pdl_sync();
         if (tid < 2 && s_red[tid]) atomicAdd(&a.counters[tid], (unsigned long long) s_red[tid]);
         if constexpr (GENOMES) {
             if (lds_table) for (uint32_t i = tid; i < a.n_genomes; i += GW_THREADS) {
@@ -651,11 +651,11 @@ __global__ __launch_bounds__(GW_THREADS) void k_group_waves(GroupTileArgs a) {
     } else {
         __shared__ unsigned long long s_own;
         if (tid == 0) s_own = 0;
-        __syncthreads();
+        pdl_sync();
 #pragma unroll
         for (int d = PDL_WAVE / 2; d > 0; d >>= 1) own_lookups += __shfl_xor(own_lookups, d, PDL_WAVE);
         if (lane == 0 && own_lookups) atomicAdd(&s_own, own_lookups);
-        __syncthreads();
+        pdl_sync();
         if (tid == 0 && s_own) atomicAdd(&a.counters[2], s_own);
     }
 }
@@ -698,7 +698,7 @@ __global__ __launch_bounds__(GW_THREADS) void k_range_count(GroupTileArgs a) {
     const uint32_t n_iv = (MODE == 0 || MODE == 2) ? a.n_own_iv : 0u;
     if constexpr (MODE == 0 || MODE == 2) { for (uint32_t i = threadIdx.x; i < n_iv; i += GW_THREADS) s_iv[i] = a.own_iv[i]; }
     if (threadIdx.x < 2) s_red[threadIdx.x] = 0;
-    __syncthreads();
+    pdl_sync();
     const uint32_t tid = threadIdx.x, lane = tid & (PDL_WAVE - 1);
     const uint32_t gw = blockIdx.x * GW_WAVES + tid / PDL_WAVE;
     const uint32_t n = (uint32_t) scan_count(a.n_bound, a.d_n);
@@ -765,7 +765,7 @@ __global__ __launch_bounds__(GW_THREADS) void k_range_count(GroupTileArgs a) {
 #pragma unroll
     for (int d = PDL_WAVE / 2; d > 0; d >>= 1) { n_rec += __shfl_xor(n_rec, d, PDL_WAVE); n_grp += __shfl_xor(n_grp, d, PDL_WAVE); }
     if (lane == 0) { atomicAdd(&s_red[0], n_rec); atomicAdd(&s_red[1], n_grp); }
-    __syncthreads();
+    pdl_sync();
     if (tid < 2 && s_red[tid]) atomicAdd(&a.counters[tid], (unsigned long long) s_red[tid]);
 }
 
@@ -786,7 +786,7 @@ __global__ __launch_bounds__(GW_THREADS) void k_range_count_hist(GroupTileArgs a
     uint32_t n_rec = 0, n_grp = 0;
     for (uint32_t blk = blockIdx.x; blk < n_tiles4; blk += gridDim.x) {       // (uniform loop: barriers inside)
         s_h[tid] = 0;
-        __syncthreads();
+        pdl_sync();
         const uint32_t tile = blk * GW_WAVES + wave, t0 = tile * GW_TILE;
         if (t0 < n) {                                     // (wave-uniform)
             uint2 po[GW_ROUNDS];
@@ -819,13 +819,13 @@ __global__ __launch_bounds__(GW_THREADS) void k_range_count_hist(GroupTileArgs a
             }
             if (lane == 0) { a.tile_sums[tile] = cnt; a.th_first[tile] = first_h; a.th_last[tile] = any_h ? last_h : GT_NONE; }
         }
-        __syncthreads();
+        pdl_sync();
         counts[(size_t) tid * n_tiles4 + blk] = s_h[tid];
     }
 #pragma unroll
     for (int d = PDL_WAVE / 2; d > 0; d >>= 1) { n_rec += __shfl_xor(n_rec, d, PDL_WAVE); n_grp += __shfl_xor(n_grp, d, PDL_WAVE); }
     if (lane == 0) { atomicAdd(&s_red[0], n_rec); atomicAdd(&s_red[1], n_grp); }
-    __syncthreads();
+    pdl_sync();
     if (tid < 2 && s_red[tid]) atomicAdd(&a.counters[tid], (unsigned long long) s_red[tid]);
 }
 
@@ -847,7 +847,7 @@ __global__ __launch_bounds__(GW_THREADS) void k_range_scatter(GroupTileArgs a, u
     for (int w = 0; w < GW_WAVES; w++) s_cnt[w][tid] = 0;
     s_goff[tid] = offs[(size_t) tid * n_tiles4 + blockIdx.x];
     if (tid == 0) s_own = 0;
-    __syncthreads();
+    pdl_sync();
 
     const unsigned long long lt_mask = (1ull << lane) - 1ull, le_mask = (2ull << lane) - 1ull;
     uint2 po[GW_ROUNDS];
@@ -940,7 +940,7 @@ __global__ __launch_bounds__(GW_THREADS) void k_range_scatter(GroupTileArgs a, u
         rank[j] = (uint16_t) (seen + (uint32_t) __popcll(same & lt_mask));
         if (valid && (same & lt_mask) == 0) s_cnt[wave][d] = (uint16_t) (seen + (uint32_t) __popcll(same));      // lowest lane of the set
     }
-    __syncthreads();
+    pdl_sync();
     uint32_t tot = 0;
     uint32_t wcnt[GW_WAVES];
 #pragma unroll
@@ -951,7 +951,7 @@ __global__ __launch_bounds__(GW_THREADS) void k_range_scatter(GroupTileArgs a, u
     uint32_t run = ex;
 #pragma unroll
     for (int w = 0; w < GW_WAVES; w++) { s_cnt[w][tid] = (uint16_t) run; run += wcnt[w]; }
-    __syncthreads();
+    pdl_sync();
 #pragma unroll
     for (int j = 0; j < GW_ROUNDS; j++) {
         if ((rbits >> j) & 1u) {
@@ -963,7 +963,7 @@ __global__ __launch_bounds__(GW_THREADS) void k_range_scatter(GroupTileArgs a, u
 #pragma unroll
     for (int d = PDL_WAVE / 2; d > 0; d >>= 1) own_lookups += __shfl_xor(own_lookups, d, PDL_WAVE);
     if (lane == 0 && own_lookups) atomicAdd(&s_own, own_lookups);
-    __syncthreads();
+    pdl_sync();
 #pragma unroll
     for (int j = 0; j < GW_ROUNDS; j++) {
         const uint32_t e = j * GW_THREADS + tid;                     // coalesced over the digit-sorted block
@@ -1053,7 +1053,7 @@ __global__ __launch_bounds__(256) void k_genome_cost(const unsigned long long *_
                                                      unsigned long long *__restrict__ max_kseq, unsigned long long *__restrict__ min_kseq) {
     __shared__ unsigned long long s_sum, s_max, s_min;
     if (threadIdx.x == 0) { s_sum = 0; s_max = 0; s_min = ~0ull; }
-    __syncthreads();
+    pdl_sync();
     const uint32_t lane = threadIdx.x & (PDL_WAVE - 1);
     unsigned long long ksum = 0, kmax = 0, kmin = ~0ull;
     for (uint32_t s0 = blockIdx.x * 256; s0 < n_seq; s0 += gridDim.x * 256) {
@@ -1082,7 +1082,7 @@ __global__ __launch_bounds__(256) void k_genome_cost(const unsigned long long *_
         kmin = o < kmin ? o : kmin;
     }
     if (lane == 0) { atomicAdd(&s_sum, ksum); atomicMax(&s_max, kmax); atomicMin(&s_min, kmin); }
-    __syncthreads();
+    pdl_sync();
     if (threadIdx.x == 0 && s_sum) { atomicAdd(sum_kseq, s_sum); atomicMax(max_kseq, s_max); atomicMax(min_kseq, ~s_min); }   // min kept as a max of complements: zero-initialised like the rest
 }
 

@@ -183,6 +183,10 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : (FILTER && T_ 
     using Cfg = JoinCfg<HT_BITS_, T_, FILTER>;
     constexpr uint32_t HT = Cfg::HT, LIMIT = Cfg::LIMIT, TOUCH_CAP = Cfg::TOUCH_CAP, RB = Cfg::RB, RPT = Cfg::RPT;
     constexpr int T = T_;
+    // chunks of 64 lookups a wave has in flight per step.  Four beside the small table (95 VGPRs: five workgroups per CU); the
+    // 2048-slot tier runs three workgroups per CU on LDS grounds and has registers to spare: eight chunks = twice the postings
+    // in flight per wave, for rows whose time is the latency of those gathers (configs[4]: 31 k lookups per row)
+    constexpr uint32_t NCH = (FILTER && HT_BITS_ == 11) ? 8 : 4;
     __shared__ unsigned long long s_acc[HT];
     __shared__ uint2 s_kf[HT];                       // {column id, 0xffffffff - smallest group start that touched it}
     __shared__ uint32_t s_bm[FILTER ? Cfg::BM_WORDS : 1];
@@ -197,6 +201,10 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : (FILTER && T_ 
     __shared__ unsigned long long s_base, s_chunk_next, s_chunk_end;
 
     const uint32_t tid = threadIdx.x;
+#ifdef PDL_JOIN_CHECK
+    __shared__ uint32_t s_rowseq;
+    uint32_t my_seq = 0;
+#endif
     const uint32_t n_work = a.n_work_ptr ? *a.n_work_ptr : a.n_work;
     if (n_work == 0) return;                             // (uniform) a tier nobody handed a row to: leave before the table is cleared
     for (uint32_t i = tid; i < HT; i += T) { s_kf[i] = make_uint2(EMPTY_KEY, 0u); s_acc[i] = 0; }
@@ -293,7 +301,7 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : (FILTER && T_ 
         constexpr uint32_t NW = T / PDL_WAVE;
         const uint32_t inc = wave_inclusive_scan_u32(sum);
         if ((tid & (PDL_WAVE - 1)) == PDL_WAVE - 1) s_wave[tid / PDL_WAVE] = inc;
-        __syncthreads();
+        pdl_sync();
         uint32_t total = 0, wave_off = 0;
 #pragma unroll
         for (uint32_t w = 0; w < NW; w++) { const uint32_t t = s_wave[w]; wave_off += w < tid / PDL_WAVE ? t : 0u; total += t; }
@@ -318,7 +326,7 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : (FILTER && T_ 
             ex += len[j];
         }
         if (tid == 0) s_cum[RB] = nb == RB ? total : 0xffffffffu;
-        __syncthreads();
+        pdl_sync();
         return total;
     };
     // Walk the staged lookups; fn(posting, {group start, own count}).  Every wave owns a contiguous segment of
@@ -347,19 +355,19 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : (FILTER && T_ 
         const uint2 ws = s_wstart[wave];
         uint32_t rs = __builtin_amdgcn_readfirstlane(ws.x);        // wave-uniform: range holding lookup ch * 64
         uint32_t cum_rs = __builtin_amdgcn_readfirstlane(ws.y);    // and its first flat index
-        for (; ch < ch_end; ch += 4) {
+        for (; ch < ch_end; ch += NCH) {
             if (*(volatile uint32_t *) &s_overflow) break;
-            uint2 gm[4], po[4];
-            uint32_t adr[4], gsv[4];
-            bool live[4];
-            const uint32_t nu = min(4u, ch_end - ch);                    // chunks of this iteration (wave-uniform)
+            uint2 gm[NCH], po[NCH];
+            uint32_t adr[NCH], gsv[NCH];
+            bool live[NCH];
+            const uint32_t nu = min(NCH, ch_end - ch);                    // chunks of this iteration (wave-uniform)
             const uint32_t f_lo = ch * PDL_WAVE, f_hi = f_lo + nu * PDL_WAVE;
             // ONE read of the next 64 range starts serves all four chunks when it reaches past them (always, unless
             // the ranges average under 4 postings): the four lane->range mappings then do not wait for each other.
             const uint32_t vw = s_cum[rs + 1 + lane];                    // starts of the following ranges (all > f_lo)
             if (__builtin_amdgcn_readlane(vw, PDL_WAVE - 1) >= f_hi) {
 #pragma unroll
-                for (uint32_t u = 0; u < 4; u++) {
+                for (uint32_t u = 0; u < NCH; u++) {
                     live[u] = false;
                     if (u < nu) {                                        // wave-uniform
                         const uint32_t lo = f_lo + u * PDL_WAVE, f = lo + lane;
@@ -375,13 +383,16 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : (FILTER && T_ 
                         gm[u] = s_gm[r];
                         adr[u] = gm[u].x + off;
                         unpack(gm[u], gsv[u], r, live[u]);
+#ifdef PDL_JOIN_CHECK
+                        if (live[u] && !(s_cum[r] <= f && f < s_cum[r + 1] && off == f - s_cum[r])) atomicAdd(a.error_count, 1u);
+#endif
                     }
                 }
                 const uint32_t ce = (uint32_t) __popcll(__ballot(vw <= f_hi));             // range holding the next iteration's first lookup
                 if (ce) { cum_rs = __builtin_amdgcn_readlane(vw, ce - 1); rs += ce; }
             } else {
 #pragma unroll
-            for (uint32_t u = 0; u < 4; u++) {
+            for (uint32_t u = 0; u < NCH; u++) {
                 live[u] = false;
                 if (ch + u < ch_end) {                   // wave-uniform: all 64 lanes are active in here
                     const uint32_t f0 = (ch + u) * PDL_WAVE, f = f0 + lane;
@@ -399,6 +410,9 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : (FILTER && T_ 
                     gm[u] = s_gm[r];
                     adr[u] = gm[u].x + off;
                     unpack(gm[u], gsv[u], r, live[u]);
+#ifdef PDL_JOIN_CHECK
+                    if (live[u] && !(s_cum[r] <= f && f < s_cum[r + 1] && off == f - s_cum[r])) atomicAdd(a.error_count, 1000u);
+#endif
                     // keep the invariant "rs holds the first lookup of the next chunk": a range may start exactly there
                     const uint32_t nextb = w < PDL_WAVE ? __builtin_amdgcn_readlane(v, w) : s_cum[rs + 1 + PDL_WAVE];
                     if (nextb == f0 + PDL_WAVE) { rs += w + 1; cum_rs = nextb; }
@@ -408,17 +422,27 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : (FILTER && T_ 
             }
             PH_WAIT(); PH_MARK(5);
 #pragma unroll
-            for (uint32_t u = 0; u < 4; u++) po[u] = a.post[live[u] ? adr[u] : 0u];     // dead lanes (last chunk) read posting 0: no exec juggling
+            for (uint32_t u = 0; u < NCH; u++) po[u] = a.post[live[u] ? adr[u] : 0u];     // dead lanes (last chunk) read posting 0: no exec juggling
             PH_WAIT(); PH_MARK(6);
+#ifdef PDL_JOIN_CHECK
+            if (*(volatile uint32_t *) &s_rowseq != my_seq) atomicAdd(a.error_count, 1000000u);
+#endif
             fn4(po, gm, gsv, live);
+#ifdef PDL_JOIN_CHECK
+            if (*(volatile uint32_t *) &s_rowseq != my_seq) atomicAdd(a.error_count, 1000000u);
+#endif
         }
     };
 
     for (;;) {
-        __syncthreads();
+        pdl_sync();
         const uint32_t wi = s_next;
         const uint4 d = s_desc;
-        __syncthreads();
+#ifdef PDL_JOIN_CHECK
+        my_seq++;
+        if (tid == 0) s_rowseq = my_seq;
+#endif
+        pdl_sync();
         PH_MARK(0);
         if (wi >= n_work) break;                         // uniform: every wave leaves here
         // the next row's ticket and descriptor are fetched now and parked in registers of lane 0 until the
@@ -444,16 +468,16 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : (FILTER && T_ 
         if constexpr (!FILTER) {
             for (uint32_t b0 = 0; b0 < nr; b0 += RB) {
                 const uint32_t total = stage(e0, b0, min(RB, nr - b0));
-                walk(total, [&](const uint2 (&po)[4], const uint2 (&gm)[4], const uint32_t (&gsv)[4], const bool (&live)[4]) {
+                walk(total, [&](const uint2 (&po)[NCH], const uint2 (&gm)[NCH], const uint32_t (&gsv)[NCH], const bool (&live)[NCH]) {
 #pragma unroll
-                    for (uint32_t u = 0; u < 4; u++) {
+                    for (uint32_t u = 0; u < NCH; u++) {
                         if (!live[u]) continue;
                         uint32_t seen;
                         const uint32_t slot = find_or_insert(po[u].x, seen);
                         if (slot != NO_SLOT) add_to(slot, seen, po[u].y, gm[u].y, 0xffffffffu - gsv[u]);
                     }
                 });
-                __syncthreads();
+                pdl_sync();
             }
         } else {
             // single-sighting columns may be dropped only if nobody involved has <= 2k k-mers
@@ -480,21 +504,21 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : (FILTER && T_ 
             for (uint32_t b0 = 0; b0 < nr; b0 += RB) {
                 const uint32_t total = stage(e0, b0, min(RB, nr - b0));     // (its barriers also cover the bitmap clear)
                 PH_MARK(1);
-                walk(total, [&](const uint2 (&po)[4], const uint2 (&gm)[4], const uint32_t (&gsv)[4], const bool (&live)[4]) {
-                    bool ins[4], later[4];
-                    uint32_t old[4], bit[4];
+                walk(total, [&](const uint2 (&po)[NCH], const uint2 (&gm)[NCH], const uint32_t (&gsv)[NCH], const bool (&live)[NCH]) {
+                    bool ins[NCH], later[NCH];
+                    uint32_t old[NCH], bit[NCH];
 #pragma unroll
-                    for (uint32_t u = 0; u < 4; u++) {       // four bitmap atomics in flight
+                    for (uint32_t u = 0; u < NCH; u++) {       // four bitmap atomics in flight
                         ins[u] = live[u] && (!filter_on || max(po[u].y, gm[u].y) >= 2);
                         const uint32_t h = (po[u].x * 0x9E3779B1u) >> (32 - Cfg::BM_BITS_LOG2);
                         bit[u] = 1u << (h & 31);
                         old[u] = (live[u] && !ins[u]) ? atomicOr(&s_bm[h >> 5], bit[u]) : 0u;
                     }
                     PH_WAIT(); PH_MARK(7);
-                    unsigned long long m[4];
+                    unsigned long long m[NCH];
                     uint32_t n_later = 0;
 #pragma unroll
-                    for (uint32_t u = 0; u < 4; u++) {
+                    for (uint32_t u = 0; u < NCH; u++) {
                         later[u] = live[u] && !ins[u] && !(old[u] & bit[u]);
                         m[u] = __ballot(later[u]);
                         n_later += (uint32_t) __popcll(m[u]);
@@ -503,7 +527,7 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : (FILTER && T_ 
                     nd_w += n_later;
                     if (nd_w > wcap) s_overflow = 1;             // (wave-uniform) no room for this iteration's first sightings: next tier
 #pragma unroll
-                    for (uint32_t u = 0; u < 4; u++) {
+                    for (uint32_t u = 0; u < NCH; u++) {
                         if (later[u]) {
                             const uint32_t i = at + (uint32_t) __popcll(m[u] & lt_mask);
                             if (i < wcap) {
@@ -523,7 +547,7 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : (FILTER && T_ 
 #endif
                 });
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the wave's stores to its list have been acknowledged by L2 before it reads them back
-                __syncthreads();
+                pdl_sync();
                 PH_MARK(2);
             }
             if (!s_overflow) {
@@ -598,14 +622,14 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : (FILTER && T_ 
                     }
                 }
             }
-            __syncthreads();
+            pdl_sync();
         }
         PH_MARK(3);
         const uint32_t ntouched = min(s_ntouched, TOUCH_CAP);
         if (s_overflow) {
             // too many keys for this table: hand the row to the next tier, wipe the table
             if (tid == 0) a.overflow_rows[atomicAdd(a.overflow_count, 1u)] = p;
-            __syncthreads();
+            pdl_sync();
             for (uint32_t i = tid; i < HT; i += T) { s_kf[i] = make_uint2(EMPTY_KEY, 0u); s_acc[i] = 0; }
             if (tid == 0) { s_ntouched = 0; s_nemit = 0; s_overflow = 0; s_next = next_reg; s_desc = next_desc; }
             continue;
@@ -626,7 +650,7 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : (FILTER && T_ 
         const uint32_t my_genome = row_info.y;
         float *ms_row = a.MS + (size_t) p * a.G;
         float *cm_row = a.CM + (size_t) row_info.w * a.N;
-        __syncthreads();
+        pdl_sync();
         const unsigned long long base = s_base;
         const bool fits = base + ntouched <= a.st_cap;
         for (uint32_t t = tid; t < ntouched; t += T) {
@@ -669,7 +693,7 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : (FILTER && T_ 
                 }
             }
         }
-        __syncthreads();
+        pdl_sync();
         PH_MARK(4);
         if (tid == 0) {
             const uint32_t nemit = s_nemit;
@@ -719,14 +743,14 @@ __global__ __launch_bounds__(HBM_THREADS) void k_join_hbm(JoinArgs a) {
     if (tid == 0) { s_ntouched = 0; s_nemit = 0; s_work = 0xffffffffu; s_batch_end = 0; }
     const float threshold = 1.0f / (2.0f * (float) a.k);
     const uint32_t n_work = a.n_work_ptr ? *a.n_work_ptr : a.n_work;
-    __syncthreads();
+    pdl_sync();
     for (;;) {
         if (tid == 0) {
             uint32_t nx = s_work + 1;
             if (nx >= s_batch_end) { nx = atomicAdd(a.work_cursor, a.work_batch); s_batch_end = nx + a.work_batch; }
             s_work = nx;
         }
-        __syncthreads();
+        pdl_sync();
         const uint32_t wi = s_work;
         if (wi >= n_work) break;
         const uint32_t p = a.work[wi];
@@ -770,7 +794,7 @@ __global__ __launch_bounds__(HBM_THREADS) void k_join_hbm(JoinArgs a) {
         }
         __threadfence();      // the touched list was written with plain stores by other waves of this workgroup
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        pdl_sync();
         const uint32_t ntouched = min(s_ntouched, a.N);
         const uint32_t my_kcnt = a.kseq_len[r];
         for (uint32_t t = tid; t < ntouched; t += JOIN_THREADS) {
@@ -784,7 +808,7 @@ __global__ __launch_bounds__(HBM_THREADS) void k_join_hbm(JoinArgs a) {
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (a barrier does not wait for stores)
-        __syncthreads();
+        pdl_sync();
         const uint32_t nemit = min(s_nemit, a.N);
         if (tid == 0) {
             const unsigned long long base = atomicAdd(a.cell_cursor, (unsigned long long) nemit);
@@ -793,7 +817,7 @@ __global__ __launch_bounds__(HBM_THREADS) void k_join_hbm(JoinArgs a) {
             a.row_base[p] = fits ? (uint32_t) base : 0u;
             a.row_cnt[p] = fits ? nemit : 0u;
         }
-        __syncthreads();
+        pdl_sync();
         const unsigned long long base = s_base;
         if (base + nemit <= a.st_cap) {
             float *ms_row = a.MS + (size_t) p * a.G;
@@ -818,7 +842,7 @@ __global__ __launch_bounds__(HBM_THREADS) void k_join_hbm(JoinArgs a) {
                 }
             }
         }
-        __syncthreads();
+        pdl_sync();
         for (uint32_t t = tid; t < ntouched; t += JOIN_THREADS) {
             const uint32_t c = ld_agent(&t_touched[t]);
             if (c < a.N) {
@@ -830,7 +854,7 @@ __global__ __launch_bounds__(HBM_THREADS) void k_join_hbm(JoinArgs a) {
         if (tid == 0) { s_ntouched = 0; s_nemit = 0; }
         __threadfence();      // the zeroing stores must have landed (in L2) before the next row's atomics
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        pdl_sync();
     }
 }
 
@@ -902,7 +926,7 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_order_rows(OrderArgs a) {
     const uint32_t own = a.row_cnt[p];
     const uint32_t cnt = own + (a.mirror_cnt ? a.mirror_cnt[p] : 0u);
     if (cnt <= ORDER_WAVE_CELLS) continue;       // k_order_rows_wave's rows (uniform)
-    __syncthreads();                             // the LDS tiles of the previous row are done with
+    pdl_sync();                             // the LDS tiles of the previous row are done with
     const uint32_t out0 = a.fin_off[p];
     const uint32_t row = a.task_rows[p];
     if (cnt <= ORDER_TILE) {
@@ -923,7 +947,7 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_order_rows(OrderArgs a) {
             }
             s_idx[j] = (uint16_t) j;
         }
-        __syncthreads();
+        pdl_sync();
         for (uint32_t k = 2; k <= n2; k <<= 1) {
             for (uint32_t j = k >> 1; j > 0; j >>= 1) {
                 for (uint32_t t = threadIdx.x; t < n2 / 2; t += ORDER_THREADS) {
@@ -937,7 +961,7 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_order_rows(OrderArgs a) {
                         const uint16_t ia = s_idx[lo]; s_idx[lo] = s_idx[hi_i]; s_idx[hi_i] = ia;
                     }
                 }
-                __syncthreads();
+                pdl_sync();
             }
         }
         for (uint32_t q = threadIdx.x; q < cnt; q += ORDER_THREADS) {
@@ -966,7 +990,7 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_order_rows(OrderArgs a) {
         uint32_t rank = 0;
         for (uint32_t j0 = 0; j0 < cnt; j0 += ORDER_TILE) {
             const uint32_t tn = min((uint32_t) ORDER_TILE, cnt - j0);
-            __syncthreads();
+            pdl_sync();
             for (uint32_t j = threadIdx.x; j < tn; j += ORDER_THREADS) {
                 const OrderCell oc = order_cell(a, p, own, j0 + j);
                 const uint2 kj = cell_key(a, oc);
@@ -974,7 +998,7 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_order_rows(OrderArgs a) {
                 s_col[j] = cj;
                 s_hi[j] = order_key_hi(cj, kj.y, a.canonical);
             }
-            __syncthreads();
+            pdl_sync();
             if (live) {
                 for (uint32_t j = 0; j < tn; j++) {          // broadcast reads; the column only breaks (rare) ties
                     const unsigned long long hj = s_hi[j];
@@ -1116,7 +1140,7 @@ template <bool SCATTER>
 __global__ __launch_bounds__(256) void k_outbox(OutboxArgs a) {
     __shared__ uint32_t s_cnt[PDL_MAX_WORLD];
     if (threadIdx.x < PDL_MAX_WORLD) s_cnt[threadIdx.x] = SCATTER && threadIdx.x < a.world ? a.offs[(size_t) threadIdx.x * a.n_blocks + blockIdx.x] : 0u;
-    __syncthreads();
+    pdl_sync();
     const uint32_t p0 = blockIdx.x * a.rows_per_block, p1 = min(a.n_rows, p0 + a.rows_per_block);
     const uint32_t lane = threadIdx.x & (PDL_WAVE - 1);
     for (uint32_t p = p0 + threadIdx.x / PDL_WAVE; p < p1; p += 256 / PDL_WAVE) {
@@ -1131,7 +1155,7 @@ __global__ __launch_bounds__(256) void k_outbox(OutboxArgs a) {
         }
     }
     if constexpr (!SCATTER) {
-        __syncthreads();
+        pdl_sync();
         if (threadIdx.x < a.world) a.tab[(size_t) threadIdx.x * a.n_blocks + blockIdx.x] = s_cnt[threadIdx.x];
     }
 }

@@ -43,16 +43,16 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_u32(uint32_t v, uint32_
     const int nw = blockDim.x / PDL_WAVE;
     uint32_t inc = wave_inclusive_scan_u32(v);
     if (lane == PDL_WAVE - 1) s_wave[wave] = inc;
-    __syncthreads();
+    pdl_sync();
     if (threadIdx.x == 0) {
         uint32_t run = 0;
         for (int w = 0; w < nw; w++) { uint32_t t = s_wave[w]; s_wave[w] = run; run += t; }
         s_wave[16] = run;
     }
-    __syncthreads();
+    pdl_sync();
     uint32_t res = inc - v + s_wave[wave];
     total = s_wave[16];
-    __syncthreads();
+    pdl_sync();
     return res;
 }
 
@@ -90,7 +90,7 @@ static __global__ __launch_bounds__(1024) void k_scan_tile_scan(uint32_t *tile_s
     __shared__ uint32_t s_wave[17];
     __shared__ uint32_t s_carry;
     if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
+    pdl_sync();
     for (uint32_t base = 0; base < n_tiles; base += 1024) {
         uint32_t i = base + threadIdx.x;
         uint32_t v = i < n_tiles ? tile_sums[i] : 0;
@@ -98,9 +98,9 @@ static __global__ __launch_bounds__(1024) void k_scan_tile_scan(uint32_t *tile_s
         uint32_t ex = block_exclusive_scan_u32(v, s_wave, total);
         uint32_t carry = s_carry;
         if (i < n_tiles) tile_sums[i] = ex + carry;
-        __syncthreads();
+        pdl_sync();
         if (threadIdx.x == 0) s_carry = carry + total;
-        __syncthreads();
+        pdl_sync();
     }
     if (threadIdx.x == 0) {
         *d_total = s_carry;
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(FlagF flag, ApplyF 
         const uint32_t f = flag(i < n ? i : n - 1);
         s_flags[li] = i < n ? f : 0u;
     }
-    __syncthreads();
+    pdl_sync();
     uint32_t f[SCAN_ITEMS];
     uint32_t sum = 0;
 #pragma unroll
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(FlagF flag, ApplyF 
     uint32_t prefix = block_exclusive_scan_u32(sum, s_wave, total) + tile_prefix;
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; j++) { s_pref[threadIdx.x * SCAN_ITEMS + j] = prefix; prefix += f[j]; }
-    __syncthreads();
+    pdl_sync();
     if constexpr (scan_two_phase<ApplyF>::value) {
         // the functor splits into load(i, flag) -> Loaded and store(i, flag, prefix, Loaded): every load of the tile's
         // items is issued before the first store, so the items' dependent load chains overlap (behind a store the

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const KeyT *__restrict__
         return;
     }
     s_h[threadIdx.x] = 0;
-    __syncthreads();
+    pdl_sync();
     KeyT key[RS_ROUNDS];
 #pragma unroll
     for (int j = 0; j < RS_ROUNDS; j++) {            // all sixteen loads in flight before the first LDS atomic
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const KeyT *__restrict__
         const uint64_t i = base + (uint64_t) j * RS_THREADS + threadIdx.x;
         if (i < n) atomicAdd(&s_h[rs_digit(key[j], shift)], 1u);
     }
-    __syncthreads();
+    pdl_sync();
     counts[(size_t) threadIdx.x * n_tiles + blockIdx.x] = s_h[threadIdx.x];
 }
 
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const KeyT *__restric
     const uint64_t wave_base = tile_base + (uint64_t) wave * RS_WAVE_SPAN;
     for (int w = 0; w < RS_WAVES; w++) s_cnt[w][tid] = 0;
     s_goff[tid] = offs[(size_t) tid * n_tiles + blockIdx.x];
-    __syncthreads();
+    pdl_sync();
 
     KeyT key[RS_ROUNDS];
     ValT val[RS_ROUNDS];
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const KeyT *__restric
         rank[j] = (uint16_t) (before + (uint32_t) __popcll(same & below));
         if (valid && (same & below) == 0) s_cnt[wave][d] = before + (uint32_t) __popcll(same);   // lowest lane of the set
     }
-    __syncthreads();
+    pdl_sync();
     // tile-level layout: digit runs in digit order, inside a run wave 0's elements first
     uint32_t tot = 0;
     uint32_t wcnt[RS_WAVES];
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const KeyT *__restric
     uint32_t run = ex;
 #pragma unroll
     for (int w = 0; w < RS_WAVES; w++) { s_cnt[w][tid] = run; run += wcnt[w]; }
-    __syncthreads();
+    pdl_sync();
 #pragma unroll
     for (int j = 0; j < RS_ROUNDS; j++) {
         const uint64_t i = wave_base + (uint64_t) j * PDL_WAVE + lane;
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const KeyT *__restric
             s_val[lp] = val[j];
         }
     }
-    __syncthreads();
+    pdl_sync();
 #pragma unroll
     for (int j = 0; j < RS_ROUNDS; j++) {
         const uint32_t e = j * RS_THREADS + tid;                      // coalesced over the digit-sorted tile

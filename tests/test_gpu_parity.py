@@ -238,6 +238,19 @@ def test_hbm_table_path_matches_fixture(name):
     H.assert_scores_equal_fixture(lambda g: nat.generate_scores_part(g).as_dict(), fx, nat.cost.genomes, name)
 
 
+@pytest.mark.parametrize("tier", [0, 9, 10, 11, 20, 21])
+@pytest.mark.parametrize("name", ["synth_16x1000x300_k5", "protein_like_12x400x150_k4_div30"])
+def test_every_first_tier_reproduces_the_reference_digests(name, tier):
+    """The join's first tier is chosen by genome count (1024 slots + filter up to 320 genomes, 2048 slots + filter and eight
+    chunks of lookups in flight beyond — the 512-genome set's kernel); the others exist for experiments.  Forced one by one
+    on sets the reference's digests pin, each must give the same cells in the same order."""
+    res, off, gen, k, d = H.load_large(name)
+    nat = _native(res, off, gen, k)
+    nat.set_option("join_tier1", tier)
+    H.assert_scores_match_digest(lambda g: nat.generate_scores_part(g).as_dict(), d, f"{name} tier {tier}")
+    assert nat.timings()["aside_reloads"] == 0 or tier in (9, 10, 11)      # (only the filter tiers keep a put-aside list)
+
+
 def test_hbm_table_path_matches_oracle_on_dense_set():
     """k=2 on 1500 genes: every gene shares k-mers with every other one (candidate sets ~ N)."""
     from oracle import binding as ob

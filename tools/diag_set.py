@@ -13,20 +13,39 @@ from pandelos_amd.synth import CONFIGS, make_gene_set
 
 name = sys.argv[1] if len(sys.argv) > 1 else "salmonella7_standin"
 passes = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-gs = make_gene_set(**CONFIGS[name]); k = calculate_k(gs.residues)
+options = [o.split("=") for o in sys.argv[3:]]                  # name=value ... (pdl_set_option)
+if name in CONFIGS:
+    shape = CONFIGS[name]
+else:
+    import json
+    shape = json.loads((ROOT / "tests" / "golden" / "digests.json").read_text())[name]["shape"]
+gs = make_gene_set(**shape); k = calculate_k(gs.residues)
 ora = ob.Oracle(gs.residues, gs.offsets, gs.genome_of, k)
 want = [ora.scores(g) for g in range(gs.genomes)]
 F = ("scores", "percs", "tr_percs", "row", "column", "max_genome_score", "max_genome_score_col")
-nat = PangeneNative.from_arrays(k, gs.residues, gs.offsets, gs.genome_of)
+nat = PangeneNative.open()
+for o, v in options:
+    nat.set_option(o, int(v))
 for it in range(passes):
-    if it:
-        nat.preprocess(k, gs.residues, gs.offsets, gs.genome_of)
+    nat.preprocess(k, gs.residues, gs.offsets, gs.genome_of)
     bad = 0
     for g in range(gs.genomes):
         s = nat.generate_scores_part(g)
         w = want[g]
         if s.scoresCount != int(w["scoresCount"]):
-            print(f"pass {it} genome {g}: count {s.scoresCount} != {int(w['scoresCount'])}"); bad += 1; continue
+            print(f"pass {it} genome {g}: count {s.scoresCount} != {int(w['scoresCount'])}"); bad += 1
+            ka = (s.row.astype(np.int64) << 32) | s.column; kb = (w["row"].astype(np.int64) << 32) | w["column"]
+            extra, missing = np.setdiff1d(ka, kb), np.setdiff1d(kb, ka)
+            for tag, ks, src in (("extra", extra, s), ("missing", missing, None)):
+                for kk in ks[:6]:
+                    r, c = int(kk >> 32), int(kk & 0xffffffff)
+                    line = f"   {tag} cell row {r} (genome {int(gs.genome_of[r])}) col {c} (genome {int(gs.genome_of[c])})"
+                    if src is not None:
+                        i = int(np.nonzero(ka == kk)[0][0]); line += f" score {src.scores[i]:.6f} perc {src.percs[i]:.6f} tr {src.tr_percs[i]:.6f}"
+                    else:
+                        i = int(np.nonzero(kb == kk)[0][0]); line += f" score {w['scores'][i]:.6f} perc {w['percs'][i]:.6f} tr {w['tr_percs'][i]:.6f}"
+                    print(line)
+            continue
         for f in F:
             a, b = np.asarray(getattr(s, f)).reshape(-1), np.asarray(w[f]).reshape(-1)
             if a.dtype == np.float32: a, b = a.view(np.uint32), b.view(np.uint32)

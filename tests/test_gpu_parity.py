@@ -251,6 +251,26 @@ def test_every_first_tier_reproduces_the_reference_digests(name, tier):
     assert nat.timings()["aside_reloads"] == 0 or tier in (9, 10, 11)      # (only the filter tiers keep a put-aside list)
 
 
+def test_more_than_320_genomes_take_the_2048_slot_tier_and_match_the_oracle():
+    """The tier a 512-genome set gets by itself (no option): 2048 slots + filter, three workgroups per CU, eight chunks of
+    lookups in flight.  330 small genomes, scored three times over (the wrong cells this tier once produced came and went
+    with the timing), every genome against the CPU oracle."""
+    from oracle import binding as ob
+    from pandelos_amd.calculate_k import calculate_k
+    from pandelos_amd.synth import make_gene_set
+    gs = make_gene_set(genomes=330, genes_per_genome=36, mean_len=90, sub_rate=0.1, seed=3301)
+    k = calculate_k(gs.residues)
+    ora = ob.Oracle(gs.residues, gs.offsets, gs.genome_of, k)
+    want = [ora.scores(g) for g in range(ora.genomes)]
+    nat = _native(gs.residues, gs.offsets, gs.genome_of, k)
+    for it in range(3):
+        if it:
+            nat.preprocess(k, gs.residues, gs.offsets, gs.genome_of)
+        assert nat.cost.total_cost == ora.total_cost
+        for g in range(ora.genomes):
+            H.assert_scores_equal(nat.generate_scores_part(g).as_dict(), want[g], f"pass {it} genome {g}")
+
+
 def test_hbm_table_path_matches_oracle_on_dense_set():
     """k=2 on 1500 genes: every gene shares k-mers with every other one (candidate sets ~ N)."""
     from oracle import binding as ob

@@ -1391,7 +1391,14 @@ static ScorePlan score_plan(pdl_ctx *c) {
     pl.grid1 = tier1 ? std::min<uint32_t>(n_rows, (uint32_t) cus * c->occ_tier1[pl.occ_slot]) : 0;
     if (c->opt_grid_pct > 0 && pl.grid1) pl.grid1 = std::max<uint32_t>(1, (uint32_t) ((uint64_t) pl.grid1 * (uint32_t) c->opt_grid_pct / 100));     // (experiments: fewer rows in flight)
     pl.grid2 = std::min<uint32_t>(n_rows, (uint32_t) cus * (pl.tiny_tier2 ? 4 : 1));
-    pl.grid3 = (uint32_t) std::min<int>(cus, 64);
+    // tier 3: a direct-addressed table per workgroup (20 bytes per gene; 36 with 32-bit counters): as many workgroups as ~8 GB
+    // of tables allow, at least 64 (configs[4]: 2 778 rows of the first genomes end up here, 0.6 ms each — 64 workgroups took
+    // 26.7 ms over them)
+    {
+        const unsigned long long per_wg = (unsigned long long) std::max<uint32_t>(N, 1) * ((pl.wide ? 2 : 1) * sizeof(uint64_t) + 3 * sizeof(uint32_t));
+        const unsigned long long fit = (8ull << 30) / per_wg;
+        pl.grid3 = (uint32_t) std::min<unsigned long long>((unsigned long long) cus, std::max<unsigned long long>(64, fit));
+    }
     const size_t hbm_bytes = (size_t) pl.grid3 * N * ((pl.wide ? 2 : 1) * sizeof(uint64_t) + 3 * sizeof(uint32_t));
     if (c->glb_table.bytes < hbm_bytes) { c->glb_table.alloc(hbm_bytes); c->glb_clean = false; }
     if (!c->glb_clean) {      // k_join_hbm leaves its tables zeroed: one memset per allocation

@@ -110,4 +110,7 @@ CONFIGS = {
     "mycoplasma64_standin": dict(genomes=64, genes_per_genome=750, mean_len=370, sub_rate=0.25, seed=6401),
     "synthetic_128x4000x300": dict(genomes=128, genes_per_genome=4000, mean_len=300, sub_rate=0.08, seed=4001),
     "synthetic_512x5000x350": dict(genomes=512, genes_per_genome=5000, mean_len=350, sub_rate=0.08, seed=5001),
+    # not a BASELINE config: a set of more than 320 genomes the reference CAN process here, so that the join tier configs[4]
+    # runs on (2048 slots + filter) is pinned by reference digests too (tests/golden/digests_baseline.json)
+    "manygenomes_384x400x160": dict(genomes=384, genes_per_genome=400, mean_len=160, sub_rate=0.08, seed=3841),
 }

@@ -7,7 +7,9 @@ The HIP path must reproduce every digest.  For the canonical 64-genome set the .
 equal the fixture byte for byte — the gene families after netclu_ng.py (.clus fixture beside it, made with the
 reference's script) are then identical by construction.
 
-configs[4] (512 x 5000 x 350) is not pinned: the reference needs ~60 GB for it in the build container (64 GB, no swap)."""
+configs[4] (512 x 5000 x 350) is not pinned: the reference needs ~60 GB for it in the build container (64 GB, no swap).
+What pins its code path instead: manygenomes_384x400x160, a set of more than 320 genomes (the join tier of configs[4]) the
+reference can process here."""
 import gzip
 import json
 
@@ -53,6 +55,15 @@ def test_config_matches_the_reference_digests(name):
 @pytest.mark.timeout(900)
 def test_config3_128x4000x300_matches_the_reference_digests():
     _check("synthetic_128x4000x300")
+
+
+@pytest.mark.skipif("manygenomes_384x400x160" not in BASE, reason="digests of the 384-genome set not generated")
+@pytest.mark.parametrize("world", [1, 4])
+def test_more_than_320_genomes_match_the_reference_digests(world):
+    """Not a BASELINE config: 384 genomes x 400 genes x 160 aa, a set the reference can process in the build container and that
+    takes the join's 2048-slot filter tier by itself — the kernel configs[4] runs on, whose own results nothing can pin.
+    One GPU and four ranks, every digest of the reference."""
+    _check("manygenomes_384x400x160", world)
 
 
 @pytest.mark.parametrize("world", [2, 8])

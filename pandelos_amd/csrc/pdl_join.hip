@@ -187,6 +187,7 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : (FILTER && T_ 
     // 2048-slot tier runs three workgroups per CU on LDS grounds and has registers to spare: eight chunks = twice the postings
     // in flight per wave, for rows whose time is the latency of those gathers (configs[4]: 31 k lookups per row)
     constexpr uint32_t NCH = (FILTER && HT_BITS_ == 11) ? 8 : 4;
+    constexpr bool PROBE2 = FILTER && HT_BITS_ == 11;        // the table is probed two slots at a time
     __shared__ unsigned long long s_acc[HT];
     __shared__ uint2 s_kf[HT];                       // {column id, 0xffffffff - smallest group start that touched it}
     __shared__ uint32_t s_bm[FILTER ? Cfg::BM_WORDS : 1];
@@ -230,27 +231,61 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : (FILTER && T_ 
 #endif
     // insert column c if it has no slot yet; returns the slot (table can never be full, see TOUCH_CAP), NO_SLOT once the row has overflowed
     constexpr uint32_t NO_SLOT = 0xffffffffu;
+    // claim the empty slot `slot` for column c: true = c sits there now (by this thread or by another one that was faster)
+    auto claim = [&](uint32_t slot, uint32_t c, bool &give_up) -> bool {
+        // a look at the key count on the (rare) insert path bounds the table: every thread that passes adds at most
+        // one key before it looks again, so there are never more than LIMIT + T of them — and no lookup has to poll
+        // the overflow flag (an LDS read per lookup, on a kernel whose LDS pipe is the busy one)
+        if (*(volatile uint32_t *) &s_ntouched >= LIMIT) { s_overflow = 1; give_up = true; return false; }
+        const uint32_t old = atomicCAS(&s_kf[slot].x, EMPTY_KEY, c);
+        if (old == EMPTY_KEY) {
+            const uint32_t idx = atomicAdd(&s_ntouched, 1u);
+            if (idx < TOUCH_CAP) s_touched[idx] = (uint16_t) slot;
+            if (idx >= LIMIT) s_overflow = 1;
+            return true;
+        }
+        return old == c;
+    };
     auto find_or_insert = [&](uint32_t c, uint32_t &seen_first) -> uint32_t {
         uint32_t slot = (c * 2654435761u) >> (32 - HT_BITS_);
+        if constexpr (PROBE2) {
+            // two slots per look (the big table's rows are bound by instruction issue, and this loop runs as often as its
+            // unluckiest lane needs: half the trips for one more LDS read each)
+            for (;;) {
+                const uint32_t slot1 = (slot + 1) & (HT - 1);
+                const uint2 k0 = s_kf[slot], k1 = s_kf[slot1];
+                if (k0.x == c) { seen_first = k0.y; return slot; }
+                bool give_up = false;
+                if (k0.x == EMPTY_KEY) {
+                    seen_first = 0;
+                    if (claim(slot, c, give_up)) return slot;
+                    if (give_up) return NO_SLOT;
+                    // (someone else took it for another column: on to the next slot, whose key was read BEFORE that — look again)
+                    slot = slot1;
+                    continue;
+                }
+                if (k1.x == c) { seen_first = k1.y; return slot1; }
+                if (k1.x == EMPTY_KEY) {
+                    seen_first = 0;
+                    if (claim(slot1, c, give_up)) return slot1;
+                    if (give_up) return NO_SLOT;
+                    slot = (slot1 + 1) & (HT - 1);
+                    continue;
+                }
+                slot = (slot1 + 1) & (HT - 1);
+            }
+        } else {
         for (;;) {
             const uint2 kf = s_kf[slot];
             seen_first = kf.y;
             if (kf.x == c) return slot;
             if (kf.x == EMPTY_KEY) {
-                // a look at the key count on the (rare) insert path bounds the table: every thread that passes adds at most
-                // one key before it looks again, so there are never more than LIMIT + T of them — and no lookup has to poll
-                // the overflow flag (an LDS read per lookup, on a kernel whose LDS pipe is the busy one)
-                if (*(volatile uint32_t *) &s_ntouched >= LIMIT) { s_overflow = 1; return NO_SLOT; }
-                const uint32_t old = atomicCAS(&s_kf[slot].x, EMPTY_KEY, c);
-                if (old == EMPTY_KEY) {
-                    const uint32_t idx = atomicAdd(&s_ntouched, 1u);
-                    if (idx < TOUCH_CAP) s_touched[idx] = (uint16_t) slot;
-                    if (idx >= LIMIT) s_overflow = 1;
-                    return slot;
-                }
-                if (old == c) return slot;
+                bool give_up = false;
+                if (claim(slot, c, give_up)) return slot;
+                if (give_up) return NO_SLOT;
             }
             slot = (slot + 1) & (HT - 1);
+        }
         }
     };
     auto add_to = [&](uint32_t slot, uint32_t seen_first, uint32_t cc, uint32_t mc, uint32_t finv) {

@@ -964,6 +964,49 @@ __global__ __launch_bounds__(ORDER_THREADS) void k_order_rows(OrderArgs a) {
     pdl_sync();                             // the LDS tiles of the previous row are done with
     const uint32_t out0 = a.fin_off[p];
     const uint32_t row = a.task_rows[p];
+    if (a.pack_ok && cnt <= 512) {
+        // rows of 257 to 512 cells (every row of a 512-genome set) when gene ids fit 22 bits: the 55-bit packed key and the
+        // cell's 9-bit index are ONE 64-bit word — the bitonic network swaps one LDS array instead of three, compares once
+        // (the index makes every key unique), and the column comes back out of the key
+        for (uint32_t j = threadIdx.x; j < 512; j += ORDER_THREADS) {
+            unsigned long long key = ~0ull;                      // padding sorts last
+            if (j < cnt) {
+                const uint2 kj = cell_key(a, order_cell(a, p, own, j));
+                key = (order_key_packed(kj.x, kj.y, a.canonical) << 9) | j;
+            }
+            s_hi[j] = key;
+        }
+        pdl_sync();
+        uint32_t prev_j = 2 * PDL_WAVE;
+        bool first = true;
+        for (uint32_t k = 2; k <= 512; k <<= 1) {
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                if (!first) {
+                    if (j > PDL_WAVE || prev_j > PDL_WAVE) pdl_sync();             // (see the general network below)
+                    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                first = false; prev_j = j;
+                const uint32_t t = threadIdx.x;                   // 256 pairs, one per thread
+                const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi_i = lo | j;
+                const unsigned long long ka = s_hi[lo], kb = s_hi[hi_i];
+                if ((ka > kb) == ((lo & k) == 0)) { s_hi[lo] = kb; s_hi[hi_i] = ka; }
+            }
+        }
+        pdl_sync();
+        for (uint32_t q = threadIdx.x; q < cnt; q += ORDER_THREADS) {
+            const unsigned long long key = s_hi[q];
+            const unsigned long long pk = key >> 9;
+            const uint32_t col = a.canonical ? (uint32_t) pk : ((uint32_t) (pk >> 44) << 11) + (uint32_t) (pk & 0xfffu);
+            const OrderCell me = order_cell(a, p, own, (uint32_t) (key & 511u));
+            const uint32_t o = out0 + q;
+            float v_score, v_perc, v_tr;
+            cell_values(a, me, v_score, v_perc, v_tr);
+            a.c_score[o] = v_score; a.c_perc[o] = v_perc; a.c_tr[o] = v_tr;
+            a.c_row[o] = (int32_t) row;
+            a.c_col[o] = (int32_t) col;
+        }
+        continue;
+    }
     if (cnt <= ORDER_TILE) {
         // bitonic sort of the row's keys in LDS (keys are unique: the column is part of them); position q of the sorted
         // order then fetches its cell and writes output slot q — coalesced writes, O(n log^2 n) compares

@@ -81,11 +81,11 @@ def test_hip_matches_oracle_on_random_sets(shape, k):
         H.assert_scores_equal(nat.generate_scores_part(g).as_dict(), ora.scores(g), f"genome {g}")
 
 
-@pytest.mark.parametrize("genomes,per_genome,floor", [(100, 3, 64), (300, 3, 256), (2100, 1, 2048)])
+@pytest.mark.parametrize("genomes,per_genome,floor", [(100, 3, 64), (300, 3, 256), (420, 1, 300), (2100, 1, 2048)])
 def test_wide_rows_keep_the_reference_emission_order(genomes, per_genome, floor):
-    """K-order ranks rows of <= 256 cells inside one wave (up to 4 cells per lane), rows of <= 2048 cells with a bitonic
-    sort in LDS, and anything wider by counting: `genomes` genomes sharing the same gene families give every row
-    ~`genomes` cells."""
+    """K-order ranks rows of <= 256 cells inside one wave (up to 4 cells per lane), rows of <= 512 cells with a bitonic sort of
+    single 64-bit words (key + index), rows of <= 2048 cells with the three-array bitonic sort, and anything wider by
+    counting: `genomes` genomes sharing the same gene families give every row ~`genomes` cells."""
     from oracle import binding as ob
     from pandelos_amd.synth import make_gene_set
     gs = make_gene_set(genomes=genomes, genes_per_genome=per_genome, mean_len=90, sub_rate=0.04, seed=207)
@@ -98,6 +98,8 @@ def test_wide_rows_keep_the_reference_emission_order(genomes, per_genome, floor)
         if len(got["row"]):
             widest = max(widest, int(np.bincount(np.asarray(got["row"])).max()))
     assert widest > floor
+    if genomes == 420:
+        assert widest <= 512            # (the single-word network's rows)
 
 
 def test_per_genome_device_copies_equal_the_host_mirror():

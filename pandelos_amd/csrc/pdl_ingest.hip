@@ -160,12 +160,12 @@ void faa_parse(const uint8_t *p, size_t n, const char *path, Sink &&put, FaaTabl
     }
 }
 
-void fill_ingest(pdl_ingest *out, const FaaTables &t, size_t file_bytes, double ms) {
+void fill_ingest(pdl_ingest *out, const FaaTables &t, size_t sequences, size_t genomes, size_t file_bytes, double ms) {
     memset(out, 0, sizeof(*out));
     out->file_bytes = file_bytes;
     out->residues = t.R;
-    out->sequences = (uint32_t) t.gen.size();
-    out->genomes = (uint32_t) t.names.size();
+    out->sequences = (uint32_t) sequences;
+    out->genomes = (uint32_t) genomes;
     out->k_suggested = k_from_counts(t);
     out->parse_ms = ms;
 }
@@ -226,7 +226,7 @@ int pdl_scan_faa(const char *path, pdl_ingest *out, uint8_t *residues, uint64_t 
             PDL_FAIL(PDL_ERR_ARGUMENT, "%s: %zu sequences, the buffers hold %u", path, t.gen.size(), cap_sequences);
         if (offsets) memcpy(offsets, t.off.data(), t.off.size() * 8);
         if (genome_of && !t.gen.empty()) memcpy(genome_of, t.gen.data(), t.gen.size() * 4);
-        fill_ingest(out, t, f.n, ms_since(t0));
+        fill_ingest(out, t, t.gen.size(), t.names.size(), f.n, ms_since(t0));
         return PDL_OK;
     } catch (const pdl_error &e) { pdl_set_create_error(e.msg); return e.code;
     } catch (const std::bad_alloc &) { pdl_set_create_error("host allocation failed"); return PDL_ERR_DEVICE; }
@@ -240,12 +240,10 @@ int pdl_ingest_faa(pdl_ctx *c, const char *path, pdl_ingest *out) {
         PDL_HIP(hipSetDevice(c->device));
         c->ingested = false;
         MappedFile f(path);
-        if (!c->ing_stream) {
-            PDL_HIP(hipStreamCreateWithFlags(&c->ing_stream, hipStreamNonBlocking));
-            for (int i = 0; i < 2; i++) {
-                PDL_HIP(hipHostMalloc((void **) &c->ing_pin[i], ING_CHUNK, hipHostMallocDefault));
-                PDL_HIP(hipEventCreateWithFlags(&c->ing_ev[i], hipEventDisableTiming));
-            }
+        if (!c->ing_stream) PDL_HIP(hipStreamCreateWithFlags(&c->ing_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) {       // (each piece checked by itself: a call that failed half-way leaves the rest for the next one)
+            if (!c->ing_pin[i]) PDL_HIP(hipHostMalloc((void **) &c->ing_pin[i], ING_CHUNK, hipHostMallocDefault));
+            if (!c->ing_ev[i]) PDL_HIP(hipEventCreateWithFlags(&c->ing_ev[i], hipEventDisableTiming));
         }
         // a dictionary built from the previous ingest still reads these buffers: wait for whatever the context has queued
         PDL_HIP(hipStreamSynchronize(c->stream));
@@ -261,8 +259,7 @@ int pdl_ingest_faa(pdl_ctx *c, const char *path, pdl_ingest *out) {
         PDL_HIP(hipMemcpyAsync(c->ing_off.p, c->ing_h_off.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->ing_stream));
         if (n) PDL_HIP(hipMemcpyAsync(c->ing_gen.p, c->ing_h_gen.data(), n * 4, hipMemcpyHostToDevice, c->ing_stream));
         PDL_HIP(hipStreamSynchronize(c->ing_stream));
-        t.off.clear(); t.gen = c->ing_h_gen; t.names = c->ing_genome_names;     // (fill_ingest reads the sizes)
-        fill_ingest(out, t, f.n, ms_since(t0));
+        fill_ingest(out, t, n, c->ing_genome_names.size(), f.n, ms_since(t0));
         out->offsets = c->ing_h_off.data(); out->genome_of = c->ing_h_gen.data();
         out->d_residues = c->ing_res.as<uint8_t>(); out->d_offsets = c->ing_off.as<uint64_t>(); out->d_genome_of = c->ing_gen.as<uint32_t>();
         c->ing_R = out->residues;

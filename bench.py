@@ -246,6 +246,25 @@ class Runner:
                 "iterations": len(times), "cells": cells,
                 "through": "pdl_preprocess + pdl_compute_scores for every genome, via the Python binding (one extra copy per array)"}
 
+    def host_path_native(self, iters, threads):
+        """The same wall time through the C ABI alone (pandelos_amd/lib/host_path: pdl_preprocess + a pool of host threads
+        making the G pdl_compute_scores calls, Pangenes.java:54-66) — what a compiled host pays, without the binding's copies."""
+        exe = ROOT / "pandelos_amd" / "lib" / "host_path"
+        if not exe.exists():
+            return None
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            faa = Path(td) / "set.faa"
+            self.gs.write_faa(faa)
+            try:
+                r = subprocess.run([str(exe), str(faa), str(self.k), str(threads), str(iters)], capture_output=True, text=True, timeout=300)
+            except subprocess.TimeoutExpired:
+                return None
+        if r.returncode != 0:
+            return {"error": (r.stderr or "").strip()[-200:]}
+        out = json.loads(r.stdout.strip().splitlines()[-1])
+        out["through"] = "pdl_preprocess + pdl_compute_scores for every genome from a pool of host threads, C ABI only (pandelos_amd/lib/host_path)"
+        return out
+
     def close(self):
         self.nat.close()
         del self.t_res, self.t_off, self.t_gen
@@ -374,6 +393,12 @@ def main():
         hp["value"] = m["pairs"] / (hp["ms"] / 1e3)
         hp["unit"] = "gene-pairs/s"
         out["host_path"] = hp
+        hn = run.host_path_native(9, max(1, min(8, os.cpu_count() or 1)))
+        if hn and "ms" in hn:
+            hn["value"] = m["pairs"] / (hn["ms"] / 1e3)
+            hn["unit"] = "gene-pairs/s"
+        if hn:
+            out["host_path_native"] = hn
     run.close()
 
     # ---- the set BASELINE.json shards over 8 GPUs, at this N ------------------------------------------------------

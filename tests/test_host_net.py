@@ -144,3 +144,17 @@ def test_device_filter_emits_the_hosts_edges_in_insertion_order(name):
         src, dst, sc = nat.generate_edges_part(g)
         want = PH.bbh_edges(nat.generate_scores_part(g))
         assert np.array_equal(src, want[0]) and np.array_equal(dst, want[1]) and np.array_equal(H.raw(sc), H.raw(want[2])), f"genome {g}"
+
+
+@pytest.mark.gpu
+def test_native_host_path_timer_counts_every_cell(tmp_path):
+    """pandelos_amd/lib/host_path (what bench.py's host_path_native runs): pdl_scan_faa -> pdl_preprocess -> the G
+    pdl_compute_scores calls from four host threads; the cells it received are the fixture's."""
+    import json
+    fx = dict(np.load(H.GOLDEN / "synth_5x60x80_k3.npz"))
+    faa = tmp_path / "in.faa"
+    faa.write_bytes(fx["faa"].tobytes())
+    p = subprocess.run([str(_lib.LIB_DIR / "host_path"), str(faa), str(int(fx["k"])), "4", "2"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out["cells"] == sum(len(fx[f"g{g}_scores"]) for g in range(int(fx["genomes"]))) and out["genomes"] == int(fx["genomes"])

@@ -151,6 +151,7 @@ def test_native_host_path_timer_counts_every_cell(tmp_path):
     """pandelos_amd/lib/host_path (what bench.py's host_path_native runs): pdl_scan_faa -> pdl_preprocess -> the G
     pdl_compute_scores calls from four host threads; the cells it received are the fixture's."""
     import json
+    from pandelos_amd import _lib
     fx = dict(np.load(H.GOLDEN / "synth_5x60x80_k3.npz"))
     faa = tmp_path / "in.faa"
     faa.write_bytes(fx["faa"].tobytes())

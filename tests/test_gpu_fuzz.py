@@ -77,3 +77,31 @@ def test_random_small_sets_match_the_oracle(seed):
         nat_s.preprocess(k, res, off, gen)
         for g in shard:
             H.assert_scores_equal(nat_s.generate_scores_part(g).as_dict(), want[g], f"seed {seed} shard genome {g}")
+
+
+@pytest.mark.parametrize("seed", list(range(7000, 7000 + int(os.environ.get("PDL_STRESS_SETS", "6")))))   # widen with PDL_STRESS_SETS=N
+def test_mid_size_sets_under_every_join_tier_match_the_oracle(seed):
+    """The bugs that came and went with the timing (stale put-aside entries, barriers without an LDS wait) never showed on
+    the tiny sets above: they need thousands of rows and several workgroups per CU.  Mid-size families-and-genomes sets,
+    a first tier and a grid size drawn per seed, every set scored twice straight after its dictionary build."""
+    from oracle import binding as ob
+    from pandelos_amd.calculate_k import calculate_k
+    from pandelos_amd.pangene_native import PangeneNative
+    from pandelos_amd.synth import make_gene_set
+    rng = np.random.default_rng(seed)
+    gs = make_gene_set(genomes=int(rng.integers(6, 48)), genes_per_genome=int(rng.integers(150, 500)), mean_len=int(rng.integers(70, 220)),
+                       sub_rate=float(rng.choice([0.02, 0.08, 0.2])), seed=seed, protein_like=bool(rng.random() < 0.3))
+    k = max(3, calculate_k(gs.residues) - int(rng.integers(0, 2)))
+    tier = int(rng.choice([10, 11, 11, 21, 9, 0]))
+    pct = int(rng.choice([0, 0, 70, 40]))
+    ora = ob.Oracle(gs.residues, gs.offsets, gs.genome_of, k)
+    want = [ora.scores(g) for g in range(ora.genomes)]
+    nat = PangeneNative.open()
+    nat.set_option("join_tier1", tier)
+    nat.set_option("join_grid_pct", pct)
+    for it in range(2):
+        nat.preprocess(k, gs.residues, gs.offsets, gs.genome_of)
+        assert nat.cost.total_cost == ora.total_cost
+        for g in range(ora.genomes):
+            H.assert_scores_equal(nat.generate_scores_part(g).as_dict(), want[g], f"seed {seed} tier {tier} grid {pct}% pass {it} genome {g}")
+    nat.close()

@@ -57,6 +57,22 @@ def test_config3_128x4000x300_matches_the_reference_digests():
     _check("synthetic_128x4000x300")
 
 
+@pytest.mark.skipif("synthetic_128x4000x300" not in BASE, reason="digests of configs[3] not generated")
+@pytest.mark.timeout(900)
+def test_config3_under_the_2048_slot_tier_matches_the_reference_digests():
+    """configs[3] (511 855 genes, 6.8 x 10^9 lookups, 55 M cells) pushed through the join tier that sets of more than 320
+    genomes get: the kernel of configs[4] at a scale the reference pins."""
+    from pandelos_amd.pangene_native import PangeneNative
+    d = BASE["synthetic_128x4000x300"]
+    gs = make_gene_set(**d["shape"])
+    nat = PangeneNative.open()
+    nat.set_option("join_tier1", 11)
+    nat.preprocess(d["k"], gs.residues, gs.offsets, gs.genome_of)
+    assert nat.cost.total_cost == d["total_cost"]
+    H.assert_scores_match_digest(lambda g: nat.generate_scores_part(g).as_dict(), d, "configs[3] tier 11")
+    assert nat.timings()["aside_reloads"] == 0
+
+
 @pytest.mark.skipif("manygenomes_384x400x160" not in BASE, reason="digests of the 384-genome set not generated")
 @pytest.mark.parametrize("world", [1, 4])
 def test_more_than_320_genomes_match_the_reference_digests(world):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Diagnostic: one stand-in set scored several times on the GPU, every genome's Scores compared field by field with the
-CPU oracle (test infrastructure); prints what differs (values or order).  usage: diag_set.py [config] [passes]"""
+"""Diagnostic (test infrastructure: it runs the CPU oracle, so it lives under tests/): one stand-in set scored several times on the GPU, every genome's Scores compared field by field with the
+CPU oracle (test infrastructure); prints what differs (values or order).  usage: python tests/diag_set.py [config] [passes] [option=value ...]"""
 import sys
 from pathlib import Path
 import numpy as np

@@ -28,7 +28,9 @@
 // when nothing is outstanding.
 #ifdef __HIPCC__
 __device__ __forceinline__ void pdl_sync() {
+#ifndef PDL_PLAIN_SYNCTHREADS        // (defined only by the negative control of tests/test_isa.py: the barrier as hipcc emits it by itself)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
     __syncthreads();
 }
 #endif

@@ -68,3 +68,64 @@ def assert_scores_equal(a: dict, b: dict, label=""):
         if not np.array_equal(x, y):
             bad = np.nonzero(x.reshape(-1) != y.reshape(-1))[0]
             raise AssertionError(f"{label} field {f}: {len(bad)} mismatches, first at {bad[:5]}")
+
+
+# ---- genome-pair sampling of a set too large for the reference (configs[4]) ------------------------------------------
+# A cell's three values depend on the two genes alone (their k-mer multisets under the same k and the same alphabet ranks):
+# the cells of rows of genome A against columns of genome B are the same whether the dictionary was built from all 512
+# genomes or from a handful of them — except around the reference's fold of the globally LAST record into the preceding
+# rank-group (library.cpp:300-306), which touches only cells of the gene that holds that record.  So the reference run on a
+# few genomes pins those genome pairs of the full run, once the genes holding the largest-rank k-mer (of the subset and of
+# the full set) are left out on both sides.
+LETTERS = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
+
+
+def genes_holding_the_largest_kmer(residues, offsets, k, gene_ids=None):
+    """Global ids of the genes that contain an occurrence of the largest-rank k-mer (ranks = base-20 numbers over LETTERS in
+    ascending letter order, library.cpp:96-100,134-150) among `gene_ids` (default: all genes).  Chunked: the full
+    512-genome set is 0.9 G residues."""
+    code = np.full(256, 255, np.uint8)
+    code[LETTERS] = np.arange(20, dtype=np.uint8)
+    off = np.asarray(offsets, dtype=np.int64)
+    ids = np.arange(len(off) - 1, dtype=np.int64) if gene_ids is None else np.asarray(gene_ids, dtype=np.int64)
+    best, holders = -1, []
+    step = 4096
+    for i0 in range(0, len(ids), step):
+        part = ids[i0:i0 + step]
+        contiguous = len(part) and part[-1] - part[0] + 1 == len(part)
+        for lo, hi, genes in ([(int(off[part[0]]), int(off[part[-1] + 1]), part)] if contiguous
+                              else [(int(off[g]), int(off[g + 1]), np.array([g])) for g in part]):
+            c = code[residues[lo:hi]].astype(np.int64)
+            assert c.max(initial=0) < 20
+            n = len(c) - k + 1
+            if n <= 0:
+                continue
+            v = np.zeros(n, np.int64)
+            for j in range(k):
+                v = v * 20 + c[j:j + n]
+            # k-mers must not straddle genes: position p (chunk-local) belongs to gene `gi`, valid iff p + k <= end of that gene
+            ends = off[genes + 1] - lo
+            gi = np.searchsorted(ends, np.arange(n), side="right")
+            v[np.arange(n) + k > ends[np.minimum(gi, len(ends) - 1)]] = -1
+            m = int(v.max())
+            if m > best:
+                best, holders = m, []
+            if m == best and m >= 0:
+                holders.extend(int(genes[x]) for x in np.unique(gi[v == m]))
+    return sorted(set(holders))
+
+
+def pair_cells_digest(block, first_gene_a, first_gene_b, genome_b, excluded_a=(), excluded_b=()):
+    """SHA-256 (and count) of the cells of one Scores block (rows of genome A) whose column lies in genome B, as sorted
+    (row - first gene of A, column - first gene of B, score bits, perc bits, tr bits); cells of excluded local genes left out."""
+    sel = np.asarray(block["second_seq_genome"]) == genome_b
+    r = np.asarray(block["row"])[sel].astype(np.int64) - first_gene_a
+    c = np.asarray(block["column"])[sel].astype(np.int64) - first_gene_b
+    keep = ~np.isin(r, np.asarray(list(excluded_a), dtype=np.int64)) & ~np.isin(c, np.asarray(list(excluded_b), dtype=np.int64))
+    r, c = r[keep], c[keep]
+    o = np.lexsort((c, r))
+    h = hashlib.sha256()
+    h.update(r[o].astype("<i4").tobytes()); h.update(c[o].astype("<i4").tobytes())
+    for f in ("scores", "percs", "tr_percs"):
+        h.update(raw(np.asarray(block[f])[sel][keep][o]).astype("<u4").tobytes())
+    return h.hexdigest(), int(len(r))

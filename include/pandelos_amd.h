@@ -104,6 +104,9 @@ typedef struct {
     uint64_t outbox_cells, inbox_cells;
     uint64_t aside_reloads;        /* join, filter tier: entries of a put-aside list that did not yet show what the wave had stored there
                                       when it first read them back (they are loaded again until they do) */
+    uint32_t aside_repeats;        /* scoring passes thrown away and repeated with fully tagged (16-byte) list entries because a pass with
+                                      the 10-bit tags saw a reload: no result is ever returned from such a pass */
+    uint32_t reserved0;
 } pdl_timings;
 
 PDL_API pdl_ctx *pdl_create(const pdl_config *cfg /* may be NULL */);
@@ -210,7 +213,8 @@ PDL_API int pdl_get_timings(pdl_ctx *, pdl_timings *out);
  * tier of the join launched with n % of the workgroups the chip holds, 0 = all: an experiment knob — how the join scales
  * with rows in flight), "stage_timers" 0|1 (default 1: HIP events around every stage fill the stage
  * fields of pdl_timings; 0: only the totals and the join's launch time are taken — each event pair is two marker packets
- * between dispatches, a few microseconds of idle stream on a two-millisecond step). */
+ * between dispatches, a few microseconds of idle stream on a two-millisecond step), "aside_test_reload" 0|1 (test switch: the next scoring pass
+ * behaves as if an entry of a put-aside list had needed a second look, so the repeat with fully tagged entries runs). */
 PDL_API int pdl_set_option(pdl_ctx *, const char *name, int64_t value);
 
 /* ---- multi-GPU: one context per GPU, the caller moves bytes between them (RCCL over xGMI) -----------------------

@@ -523,6 +523,7 @@ int pdl_set_option(pdl_ctx *c, const char *name, int64_t value) {
     else if (n == "stage_timers") c->opt_stage_timers = value != 0;
     else if (n == "host_mirror") c->opt_host_mirror = value != 0;
     else if (n == "staging_cap") c->opt_staging_cap = value > 0 ? (uint64_t) value : 0;
+    else if (n == "aside_test_reload") c->opt_aside_test_reload = value != 0;
     else { c->err = "unknown option " + n; return PDL_ERR_ARGUMENT; }
     c->scored = false;        // the next scoring call runs with the new setting
     return PDL_OK;

@@ -238,6 +238,7 @@ struct pdl_ctx {
     int opt_grid_pct = 0;         // > 0: tier-1 grid as a percentage of what fits the chip (experiments)
     bool opt_host_mirror = true;
     uint64_t opt_staging_cap = 0; // 0: estimate
+    bool opt_aside_test_reload = false;   // test switch: the next pass with 8-byte put-aside entries counts as one that saw a reload
 
     // multi-GPU (pdl_dist_*): this context is rank `rank` of `world`; the postings live in caller-owned memory
     bool dist = false;

@@ -289,3 +289,79 @@ class LocalRanks:
 
     def generate_scores_part(self, genome: int):
         return self.ranks[int(self.owner[genome])].generate_scores_part(genome)
+
+
+class RanksInTurn:
+    """The W ranks of a job played ONE AFTER THE OTHER on a single context — for sets whose W contexts would not fit one
+    device side by side (BASELINE configs[4]: every rank ranks all 0.9 G k-mers).  Same library calls as
+    ``DistributedPangenes``; what the exchanges would carry is kept in device tensors between the passes:
+
+      pass 1   every rank: dist_preprocess_begin                          -> its run is kept (the "all-gather")
+      pass 2   every rank: begin, finish, score_begin                     -> its outbox is kept (the "all-to-all")
+      pass 3   every rank: begin, finish, score_begin, score_finish       -> ``visit(rank, nat, genomes)`` sees its results
+
+    (``tools/shard_step_time.py`` is the timing version of the same walk.)"""
+
+    def __init__(self, world: int, nat=None):
+        from .pangene_native import PangeneNative
+        self.world = world
+        self.nat = nat or PangeneNative.open()
+
+    def run(self, k, t_res, t_off, t_gen, n_genes, n_residues, visit):
+        import torch
+        nat, W, dev = self.nat, self.world, t_res.device
+
+        def begin(r):
+            return nat.dist_preprocess_begin(k, t_res.data_ptr(), t_off.data_ptr(), t_gen.data_ptr(), n_genes, n_residues, W, r)
+
+        saved, weights = [], None
+        for r in range(W):
+            ptr, rec, _ = begin(r)
+            weights = nat.run_weights.copy() if weights is None else weights + nat.run_weights
+            run_t = torch.empty(max(rec, 1), dtype=torch.int64, device=dev)
+            if rec:
+                nat.copy_device(run_t.data_ptr(), ptr, rec * 8)
+            saved.append(run_t[:rec])
+        self.run_records = [int(t.numel()) for t in saved]
+        total = int(sum(self.run_records))
+        full0 = torch.cat(saved) if total else torch.zeros(1, dtype=torch.int64, device=dev)
+        del saved
+        full = torch.empty_like(full0)          # finish works in place (head bits, the fold of the last record): a fresh copy per rank
+
+        def upto_score_begin(r):
+            begin(r)
+            full.copy_(full0)
+            torch.cuda.synchronize(dev)
+            nat.dist_preprocess_finish(full.data_ptr(), total, genome_weights=weights)
+            return nat.dist_score_begin(W)
+
+        outbox, counts = [], []
+        self.total_cost, self.owner = 0, None
+        for r in range(W):
+            ptr, cnt = upto_score_begin(r)
+            if self.owner is None:
+                self.owner = nat.dist_genome_owner()
+            self.total_cost += int(nat.cost.total_cost)
+            n_out = int(cnt.sum())
+            box = torch.empty((max(n_out, 1), 6), dtype=torch.int32, device=dev)
+            if n_out:
+                nat.copy_device(box.data_ptr(), ptr, n_out * _lib.DIST_CELL_BYTES)
+            outbox.append(box)
+            counts.append(cnt)
+        cmat = np.stack(counts)                  # [src][dst]
+        self.outbox_counts = cmat
+        for r in range(W):
+            n_in = int(cmat[:, r].sum())
+            inbox = torch.empty((max(n_in, 1), 6), dtype=torch.int32, device=dev)
+            at = 0
+            for s in range(W):
+                c = int(cmat[s, r])
+                if c:
+                    o = int(cmat[s, :r].sum())
+                    inbox[at:at + c] = outbox[s][o:o + c]
+                    at += c
+            upto_score_begin(r)
+            nat.dist_score_finish(inbox.data_ptr(), n_in, keepalive=inbox)
+            visit(r, nat, [int(g) for g in np.nonzero(self.owner == r)[0]])
+            del inbox
+        del outbox, full, full0

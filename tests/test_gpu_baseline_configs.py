@@ -118,4 +118,6 @@ def test_repeated_scoring_reproduces_the_digest_every_time():
         assert got == d["scoresCount"], f"pass {it}: {[a - b for a, b in zip(got, d['scoresCount'])]}"
         if it % 4 == 0:
             H.assert_scores_match_digest(lambda g: nat.generate_scores_part(g).as_dict(), d, f"{name} pass {it}")
+        tm = nat.timings()
+        assert tm["aside_reloads"] == 0 and tm["aside_repeats"] == 0
         nat.close()

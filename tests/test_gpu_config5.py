@@ -1,0 +1,150 @@
+"""BASELINE.json configs[4] — synthetic 512 genomes x 5000 genes x 350 aa, the "HBM-roofline run" — at FULL size on one GPU
+(2.56 M genes, 0.9 G residues, 6 x 10^10 lookups, 1.1 x 10^9 cells; ~150 GB of HBM).
+
+The reference cannot process this set in the build container (~60 GB for its 16-byte records, per-pass copies and range
+triples; 64 GB, no swap), so it is pinned in three ways:
+
+  * reference-pinned SAMPLES: the cells of 41 ordered genome pairs, produced by the reference's own library.cpp on 3-4-genome
+    subsets of the set (tests/golden/config5_pairs.json, make_golden_config5_pairs.py) — a cell's values depend on its two
+    genes alone, so the full run must reproduce them (digest of the sorted cells per genome pair);
+  * the size-independent properties of tests/test_gpu_fullsize.py: "Total cost" from the dictionary's own group sizes,
+    (r, c) <-> (c, r) symmetry, per-(row, genome) / per-column maxima recomputed from the cells;
+  * agreement of every genome's Scores digest across code paths: the default first tier of the join (2048-slot filter
+    tier + put-aside lists) against the unfiltered 8192-slot tier for every row, and one GPU against eight ranks.
+
+`timings()` proves the tiers were reached: rows handed to tier 2 and to the HBM-table tier, no put-aside entry loaded twice."""
+import hashlib
+import json
+
+import numpy as np
+import pytest
+
+from pandelos_amd.calculate_k import calculate_k
+from pandelos_amd.synth import CONFIGS, make_gene_set
+from tests import helpers as H
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(1500)]
+
+NAME = "synthetic_512x5000x350"
+PAIRS = json.loads((H.GOLDEN / "config5_pairs.json").read_text())
+SAMPLE_GENOMES = (0, 255, 511)            # full property checks (every genome gets its digest compared)
+
+
+def _digest(block: dict) -> str:
+    h = hashlib.sha256()
+    for f in H.FIELDS:
+        h.update(H.raw(block[f]).tobytes())
+    return h.hexdigest()
+
+
+@pytest.fixture(scope="module")
+def state():
+    import torch
+    if torch.cuda.mem_get_info(0)[1] < 200 * 2 ** 30:
+        pytest.skip("needs ~150 GB of HBM")
+    gs = make_gene_set(**CONFIGS[NAME])
+    k = calculate_k(gs.residues)
+    assert (gs.genes, gs.genomes, k) == (PAIRS["sequences"], PAIRS["genomes"], PAIRS["k"])
+    return {"gs": gs, "k": k, "first": np.searchsorted(gs.genome_of, np.arange(gs.genomes + 1)), "digests": None}
+
+
+def _score_one_gpu(state, tier1=None):
+    from pandelos_amd.pangene_native import PangeneNative
+    gs, k = state["gs"], state["k"]
+    nat = PangeneNative.open()
+    if tier1 is not None:
+        nat.set_option("join_tier1", tier1)
+    nat.preprocess(k, gs.residues, gs.offsets, gs.genome_of)
+    nat.score_all()
+    return nat
+
+
+def test_full_run_reproduces_the_reference_pinned_genome_pairs_and_the_properties(state):
+    gs, k, first = state["gs"], state["k"], state["first"]
+    nat = _score_one_gpu(state)
+    c, tm = nat.cost, nat.timings()
+    # the tiers of the join were all reached, and no put-aside entry needed a second look
+    assert tm["aside_reloads"] == 0 and tm["aside_repeats"] == 0
+    assert tm["tier2_rows"] > 0 and tm["overflow_rows"] > 0 and tm["scored_rows"] == gs.genes
+    assert tm["emitted_cells"] == int(nat.scores_counts().astype(np.int64).sum()) > 10 ** 9
+    # "Total cost" from the dictionary's own group sizes (library.cpp:327,349), via the per-gene costs; k-mer counts
+    cost, kl = nat.sequence_costs()
+    lens = np.diff(gs.offsets.astype(np.int64))
+    assert np.array_equal(kl.astype(np.int64), np.maximum(lens - k + 1, 0))
+    assert int(cost.astype(np.uint64).sum()) == c.total_cost and c.kmer_occurrences == int(kl.sum())
+    assert tm["walked_lookups"] * 2 == c.total_cost - c.shared_records            # sum s(s-1)/2 over the groups
+    # reference-pinned genome pairs
+    assert H.genes_holding_the_largest_kmer(gs.residues, gs.offsets, k, np.arange(first[380], first[381])) is not None   # (helper runs at this size)
+    blocks, checked = {}, 0
+    for sub in PAIRS["subsets"]:
+        excl = {int(g): v for g, v in sub["excluded_local_genes"].items()}
+        for pr in sub["pairs"]:
+            a, b = pr["row_genome"], pr["col_genome"]
+            if a not in blocks:
+                blocks[a] = nat.generate_scores_part(a).as_dict()
+            dig, cnt = H.pair_cells_digest(blocks[a], int(first[a]), int(first[b]), b, excl[a], excl[b])
+            assert (cnt, dig) == (pr["cells"], pr["sha256"]), f"cells of genome pair ({a}, {b}) differ from the reference's"
+            checked += cnt
+    assert checked > 100_000
+    # properties on sampled genomes: maxima follow from the cells; mirrors of their cells sit in the mirrored genome's block
+    for g in SAMPLE_GENOMES:
+        b = blocks.get(g) or nat.generate_scores_part(g).as_dict()
+        ms = np.zeros_like(b["max_genome_score"])
+        np.maximum.at(ms, (b["scoresMaxMappings"][b["row"]], b["second_seq_genome"]), b["scores"])
+        cm = np.zeros_like(b["max_genome_score_col"])
+        np.maximum.at(cm, b["column"], b["scores"])
+        assert np.array_equal(H.raw(ms), H.raw(b["max_genome_score"])) and np.array_equal(H.raw(cm), H.raw(b["max_genome_score_col"]))
+        assert np.all(b["scores"] > 0) and np.all(np.diff(b["row"]) >= 0) and np.all(b["first_seq_genome"] == g)
+        other = 511 - g if g != 255 else 256
+        bo = nat.generate_scores_part(other).as_dict()
+        mine = b["second_seq_genome"] == other
+        theirs = bo["second_seq_genome"] == g
+        ka = b["row"][mine].astype(np.int64) * gs.genes + b["column"][mine]
+        kb = bo["column"][theirs].astype(np.int64) * gs.genes + bo["row"][theirs]
+        oa, ob_ = np.argsort(ka), np.argsort(kb)
+        assert np.array_equal(ka[oa], kb[ob_])
+        assert np.array_equal(H.raw(b["scores"][mine][oa]), H.raw(bo["scores"][theirs][ob_]))
+        assert np.array_equal(H.raw(b["percs"][mine][oa]), H.raw(bo["tr_percs"][theirs][ob_]))
+    del blocks
+    # every genome's digest, for the cross-path comparisons below
+    state["digests"] = [_digest(nat.generate_scores_part(g).as_dict()) for g in range(gs.genomes)]
+    state["total_cost"] = c.total_cost
+    nat.close()
+
+
+def test_every_row_through_the_unfiltered_8192_slot_tier_gives_the_same_digests(state):
+    if state["digests"] is None:
+        pytest.skip("the default-tier run did not complete")
+    nat = _score_one_gpu(state, tier1=0)
+    tm = nat.timings()
+    assert tm["tier2_rows"] == state["gs"].genes and tm["overflow_rows"] > 0
+    for g in range(state["gs"].genomes):
+        assert _digest(nat.generate_scores_part(g).as_dict()) == state["digests"][g], f"genome {g}: tier 0 differs from the default tier"
+    nat.close()
+
+
+def test_eight_ranks_give_the_same_digests_as_one_gpu(state):
+    if state["digests"] is None:
+        pytest.skip("the default-tier run did not complete")
+    import torch
+    from pandelos_amd.distributed import RanksInTurn
+    gs, k = state["gs"], state["k"]
+    dev = torch.device("cuda", 0)
+    pad = (-len(gs.residues)) % 16 + 16
+    t_res = torch.from_numpy(np.concatenate([gs.residues, np.zeros(pad, np.uint8)])).to(dev)
+    t_off = torch.from_numpy(gs.offsets.astype(np.int64)).to(dev)
+    t_gen = torch.from_numpy(gs.genome_of.astype(np.int32)).to(dev)
+    seen = []
+
+    def visit(rank, nat, genomes):
+        assert nat.timings()["aside_reloads"] == 0
+        for g in genomes:
+            assert _digest(nat.generate_scores_part(g).as_dict()) == state["digests"][g], f"genome {g} (rank {rank} of 8) differs from one GPU"
+            seen.append(g)
+
+    rt = RanksInTurn(8)
+    rt.run(k, t_res, t_off, t_gen, gs.genes, len(gs.residues), visit)
+    assert sorted(seen) == list(range(gs.genomes))
+    assert rt.total_cost == state["total_cost"]
+    assert 2 * int(rt.outbox_counts.sum()) > 0
+    rt.nat.close()

@@ -104,4 +104,6 @@ def test_mid_size_sets_under_every_join_tier_match_the_oracle(seed):
         assert nat.cost.total_cost == ora.total_cost
         for g in range(ora.genomes):
             H.assert_scores_equal(nat.generate_scores_part(g).as_dict(), want[g], f"seed {seed} tier {tier} grid {pct}% pass {it} genome {g}")
+        tm = nat.timings()
+        assert tm["aside_reloads"] == 0 and tm["aside_repeats"] == 0, f"seed {seed} tier {tier}: the put-aside canary went off"
     nat.close()

@@ -250,7 +250,25 @@ def test_every_first_tier_reproduces_the_reference_digests(name, tier):
     nat = _native(res, off, gen, k)
     nat.set_option("join_tier1", tier)
     H.assert_scores_match_digest(lambda g: nat.generate_scores_part(g).as_dict(), d, f"{name} tier {tier}")
-    assert nat.timings()["aside_reloads"] == 0 or tier in (9, 10, 11)      # (only the filter tiers keep a put-aside list)
+    tm = nat.timings()
+    assert tm["aside_reloads"] == 0 and tm["aside_repeats"] == 0        # the canary of the filter tiers' put-aside lists (the other tiers keep none)
+
+
+@pytest.mark.parametrize("tier", [10, 11])
+def test_a_pass_that_saw_a_reload_is_repeated_with_fully_tagged_entries(tier):
+    """The 8-byte put-aside entries carry a 10-bit tag: a stale entry passes it once in 1024.  So a pass in which any entry
+    needed a second look is never returned: it is repeated with 16-byte entries that name row and launch in full
+    (pdl_timings.aside_repeats).  No run has ever seen a reload; the test switch makes the next pass count as one that did."""
+    res, off, gen, k, d = H.load_large("synth_16x1000x300_k5")
+    nat = _native(res, off, gen, k)
+    nat.set_option("join_tier1", tier)
+    nat.set_option("aside_test_reload", 1)
+    H.assert_scores_match_digest(lambda g: nat.generate_scores_part(g).as_dict(), d, f"tier {tier}, repeated with wide entries")
+    tm = nat.timings()
+    assert tm["aside_repeats"] == 1 and tm["aside_reloads"] == 0
+    nat.set_option("join_tier1", tier)          # (any option marks the scores stale: the next pass is an ordinary one)
+    H.assert_scores_match_digest(lambda g: nat.generate_scores_part(g).as_dict(), d, f"tier {tier}")
+    assert nat.timings()["aside_repeats"] == 0
 
 
 def test_more_than_320_genomes_take_the_2048_slot_tier_and_match_the_oracle():

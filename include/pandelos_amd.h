@@ -106,7 +106,7 @@ typedef struct {
                                       when it first read them back (they are loaded again until they do) */
     uint32_t aside_repeats;        /* scoring passes thrown away and repeated with fully tagged (16-byte) list entries because a pass with
                                       the 10-bit tags saw a reload: no result is ever returned from such a pass */
-    uint32_t reserved0;
+    uint32_t tier1_rows;           /* rows that reached the filtered small-table tier (all of them unless the partition tier ran in front) */
 } pdl_timings;
 
 PDL_API pdl_ctx *pdl_create(const pdl_config *cfg /* may be NULL */);
@@ -206,6 +206,8 @@ PDL_API int pdl_get_timings(pdl_ctx *, pdl_timings *out);
 
 /* Tuning / test switches of one context (no environment variable is read by the library).  Unknown names fail with
  * PDL_ERR_ARGUMENT.  Options: "join_tier1" 0|9|10|11|20|21 (table of the join's first tier; -1 = default: by genome count),
+ * "join_tier0" -1|0|1 (the partition tier in front of tier 1 — several short rows per workgroup cycle, no hash table: -1 = by the
+ * average row length, the default; it stays off when "join_tier1" was set by hand unless forced with 1),
  * "join_tiny_tier2" 0|1 (512-slot second tier, so that small test sets reach the HBM-table kernel), "host_mirror" 0|1
  * (pdl_compute_scores slices ONE pinned copy of the whole result (1, default) or copies each genome's block from the
  * device (0); results above 1 GiB always take the second way), "staging_cap" n (cells of staging the first scoring

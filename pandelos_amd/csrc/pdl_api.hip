@@ -518,7 +518,8 @@ int pdl_set_option(pdl_ctx *c, const char *name, int64_t value) {
     if (n == "join_tier1") {
         if (!(value == -1 || value == 0 || (value >= 9 && value <= 11) || value == 20 || value == 21)) { c->err = "join_tier1: -1, 0, 9, 10, 11, 20 or 21"; return PDL_ERR_ARGUMENT; }
         c->opt_tier1 = (int) value;
-    } else if (n == "join_tiny_tier2") c->opt_tiny_tier2 = value != 0;
+    } else if (n == "join_tier0") c->opt_tier0 = value < 0 ? -1 : (value != 0);
+    else if (n == "join_tiny_tier2") c->opt_tiny_tier2 = value != 0;
     else if (n == "join_grid_pct") c->opt_grid_pct = (int) value;
     else if (n == "stage_timers") c->opt_stage_timers = value != 0;
     else if (n == "host_mirror") c->opt_host_mirror = value != 0;

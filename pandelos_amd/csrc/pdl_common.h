@@ -140,6 +140,7 @@ struct pdl_ctx {
     bool only_complexity = false;
     uint32_t N = 0, G = 0;
     uint64_t R = 0, M = 0, U = 0, Ushared = 0, NG = 0, P = 0, sum_kseq = 0, max_kseq = 0, min_kseq = 0;
+    uint64_t Urepeat = 0;          // dictionary records with a count >= 2 (the k-mer repeats inside the gene): the "heavy" lookups of the join come from these
     RankParams rp{};
 
     // K-ingest (pdl_ingest.hip): the input a .faa file was parsed into, and the two pinned staging buffers it travelled through
@@ -221,6 +222,7 @@ struct pdl_ctx {
     DevBuf task_off;      // u32 [shard+1] task offsets | gathered cell offsets + 8 counters + cell total
     int cus = 0;
     uint32_t occ_tier1[5] = {0, 0, 0, 0, 0};
+    uint32_t occ_tier0 = 0;
 
     // K-bbh (pdl_bbh.hip): network edges of every genome task, on the host after the first pdl_compute_edges
     bool edges_valid = false;
@@ -233,6 +235,7 @@ struct pdl_ctx {
 
     // tuning / test switches (pdl_set_option)
     int opt_tier1 = -1;           // -1: by genome count
+    int opt_tier0 = -1;           // the partition tier in front of tier 1: -1 by row length, 0 off, 1 on
     bool opt_tiny_tier2 = false;
     bool opt_stage_timers = true; // per-stage HIP events (pdl_timings' stage fields); the totals and the join's are always taken
     int opt_grid_pct = 0;         // > 0: tier-1 grid as a percentage of what fits the chip (experiments)

@@ -451,7 +451,7 @@ struct GroupTileArgs {
                                                 //     carried through the gene sort as its payload: no gather afterwards
     unsigned long long *head_bits;              // WRITE: [tiles * 16] the head bits it removes from the postings, kept for the lazy cost pass
     unsigned long long *cost;                   // per-gene total_visited (library.cpp:327): last members (WRITE), all shared records (COUNT, RECORD_COSTS)
-    unsigned long long *counters;               // COUNT: [0] += records in groups >= 2, [1] += such groups;  WRITE: [2] += lookups of the
+    unsigned long long *counters;               // COUNT: [0] += records in groups >= 2, [1] += such groups, [3] += records whose k-mer repeats inside its gene (range modes);  WRITE: [2] += lookups of the
                                                 //        records that belong to this context (library.cpp:327 summed: "Total cost")
     const uint32_t *genome_of; uint32_t n_genomes;
     unsigned long long *g_full, *g_upper;       // COUNT, GENOMES: per genome, lookups as the reference counts them / above the diagonal
@@ -703,7 +703,7 @@ __global__ __launch_bounds__(GW_THREADS) void k_range_count(GroupTileArgs a) {
     const uint32_t gw = blockIdx.x * GW_WAVES + tid / PDL_WAVE;
     const uint32_t n = (uint32_t) scan_count(a.n_bound, a.d_n);
     const uint32_t tiles = (n + GW_TILE - 1) / GW_TILE;
-    uint32_t n_rec = 0, n_grp = 0;
+    uint32_t n_rec = 0, n_grp = 0, n_rep = 0;
     for (uint32_t tile = gw; tile < tiles; tile += gridDim.x * GW_WAVES) {
         const uint32_t t0 = tile * GW_TILE;
         uint2 po[GW_ROUNDS];
@@ -750,7 +750,7 @@ __global__ __launch_bounds__(GW_THREADS) void k_range_count(GroupTileArgs a) {
             bool r = MODE == 0 ? shared : (live && !next_head);
             if constexpr (MODE == 0 || MODE == 2) r = r && ((ins >> j) & 1u);
             cnt += r;
-            n_rec += shared; n_grp += head && !next_head;
+            n_rec += shared; n_grp += head && !next_head; n_rep += live && (po[j].y & ~HEAD_BIT) >= 2u;
             if (head) { first_h = min(first_h, u); last_h = max(last_h, u); any_h = 1; }
         }
 #pragma unroll
@@ -763,8 +763,8 @@ __global__ __launch_bounds__(GW_THREADS) void k_range_count(GroupTileArgs a) {
         if (lane == 0) { a.tile_sums[tile] = cnt; a.th_first[tile] = first_h; a.th_last[tile] = any_h ? last_h : GT_NONE; }
     }
 #pragma unroll
-    for (int d = PDL_WAVE / 2; d > 0; d >>= 1) { n_rec += __shfl_xor(n_rec, d, PDL_WAVE); n_grp += __shfl_xor(n_grp, d, PDL_WAVE); }
-    if (lane == 0) { atomicAdd(&s_red[0], n_rec); atomicAdd(&s_red[1], n_grp); }
+    for (int d = PDL_WAVE / 2; d > 0; d >>= 1) { n_rec += __shfl_xor(n_rec, d, PDL_WAVE); n_grp += __shfl_xor(n_grp, d, PDL_WAVE); n_rep += __shfl_xor(n_rep, d, PDL_WAVE); }
+    if (lane == 0) { atomicAdd(&s_red[0], n_rec); atomicAdd(&s_red[1], n_grp); if (n_rep) atomicAdd(&a.counters[3], (unsigned long long) n_rep); }
     pdl_sync();
     if (tid < 2 && s_red[tid]) atomicAdd(&a.counters[tid], (unsigned long long) s_red[tid]);
 }
@@ -783,7 +783,7 @@ __global__ __launch_bounds__(GW_THREADS) void k_range_count_hist(GroupTileArgs a
     const uint32_t tid = threadIdx.x, lane = tid & (PDL_WAVE - 1), wave = tid / PDL_WAVE;
     const uint32_t n = (uint32_t) scan_count(a.n_bound, a.d_n);
     if (tid < 2) s_red[tid] = 0;
-    uint32_t n_rec = 0, n_grp = 0;
+    uint32_t n_rec = 0, n_grp = 0, n_rep = 0;
     for (uint32_t blk = blockIdx.x; blk < n_tiles4; blk += gridDim.x) {       // (uniform loop: barriers inside)
         s_h[tid] = 0;
         pdl_sync();
@@ -807,7 +807,7 @@ __global__ __launch_bounds__(GW_THREADS) void k_range_count_hist(GroupTileArgs a
                 const bool r = live && !next_head;
                 if (r) atomicAdd(&s_h[po[j].x & (PDL_RADIX_BINS - 1)], 1u);
                 cnt += r;
-                n_rec += live && !(head && next_head); n_grp += head && !next_head;
+                n_rec += live && !(head && next_head); n_grp += head && !next_head; n_rep += live && (po[j].y & ~HEAD_BIT) >= 2u;
                 if (head) { first_h = min(first_h, u); last_h = max(last_h, u); any_h = 1; }
             }
 #pragma unroll
@@ -823,8 +823,8 @@ __global__ __launch_bounds__(GW_THREADS) void k_range_count_hist(GroupTileArgs a
         counts[(size_t) tid * n_tiles4 + blk] = s_h[tid];
     }
 #pragma unroll
-    for (int d = PDL_WAVE / 2; d > 0; d >>= 1) { n_rec += __shfl_xor(n_rec, d, PDL_WAVE); n_grp += __shfl_xor(n_grp, d, PDL_WAVE); }
-    if (lane == 0) { atomicAdd(&s_red[0], n_rec); atomicAdd(&s_red[1], n_grp); }
+    for (int d = PDL_WAVE / 2; d > 0; d >>= 1) { n_rec += __shfl_xor(n_rec, d, PDL_WAVE); n_grp += __shfl_xor(n_grp, d, PDL_WAVE); n_rep += __shfl_xor(n_rep, d, PDL_WAVE); }
+    if (lane == 0) { atomicAdd(&s_red[0], n_rec); atomicAdd(&s_red[1], n_grp); if (n_rep) atomicAdd(&a.counters[3], (unsigned long long) n_rep); }
     pdl_sync();
     if (tid < 2 && s_red[tid]) atomicAdd(&a.counters[tid], (unsigned long long) s_red[tid]);
 }
@@ -1089,7 +1089,7 @@ __global__ __launch_bounds__(256) void k_genome_cost(const unsigned long long *_
 // ------------------------------------------------------------------------------------------------
 // Host side of the stages.  Control block words (c->scalars, u64): 0 U | 1 groups of any size | 2 ranges built |
 // 3 bad-offsets flag | 4 sum kseq | 5 M | 6 emitted cells | 7 max kseq | 8 ~min kseq | 9 mirrored cells |
-// 10 U' | 11 shared groups | 15 sort scratch | PDL_CTL_HIST.. histogram | PDL_CTL_GCOST.. per-genome cost
+// 10 U' | 11 shared groups | 12 lookups of this context's genes | 13 records whose k-mer repeats inside its gene | 15 sort scratch | PDL_CTL_HIST.. histogram | PDL_CTL_GCOST.. per-genome cost
 // ------------------------------------------------------------------------------------------------
 
 // K-hist + K-len + the rank table; leaves M, the rank parameters and the key width in the context.
@@ -1354,17 +1354,18 @@ static void stage_ranges_and_costs(pdl_ctx *c, uint64_t bound, int mode, bool on
                        reinterpret_cast<unsigned long long *>(d_scal + 8));
     PDL_HIP(hipGetLastError());
 
-    uint64_t tail[12] = {0}, tail_own = 0;
+    uint64_t tail[12] = {0}, tail_own = 0, tail_rep = 0;
     {
         PinRead rd(c);                       // one copy: the whole control block
         const uint64_t *pt = rd.add<uint64_t>(d_scal, PDL_CTL_GCOST + (size_t) c->G);
         rd.sync();
         c->h_genome_cost.assign(pt + PDL_CTL_GCOST, pt + PDL_CTL_GCOST + c->G);     // (a shard, one rank of several: its own genomes only)
         memcpy(tail, pt, sizeof(tail));
-        tail_own = pt[12];
+        tail_own = pt[12]; tail_rep = pt[13];
     }
     c->U = tail[0];
     c->Ushared = tail[10];
+    c->Urepeat = tail_rep;
     c->NG = tail[11];
     c->sum_kseq = tail[4];
     c->max_kseq = tail[7];

@@ -114,6 +114,8 @@ __device__ __forceinline__ float finalize_cell(unsigned long long acc, uint32_t 
     return (float) inter / (float) union_size * (score_valid ? 1.0f : 0.0f);
 }
 
+#include "pdl_join_part.h"       // K-join, partition tier (short rows, several per workgroup cycle)
+
 // ------------------------------------------------------------------------------------------------
 // K-join (LDS table).  Persistent workgroups pull rows (work items) from a global cursor.
 //
@@ -1338,6 +1340,7 @@ __global__ void k_gather_u32(const uint32_t *src, const uint32_t *idx, uint32_t 
     else if (i < n + 8) dst[i] = ctr[i - n];
     else if (i < n + 10) dst[i] = z64[i - n - 8];
     else if (i == n + 10) dst[i] = ctr[10];          // entries of the put-aside lists that had to be loaded again
+    else if (i == n + 11) dst[i] = ctr[12];          // rows the partition tier handed to tier 1
 }
 
 // Clears up to four arrays in one launch (16-byte words; every separate small fill is a dispatch of its own).
@@ -1394,7 +1397,7 @@ void pdl_prepare_tasks(pdl_ctx *c) {
     }
     memcpy(c->task_pin + words, c->h_task_row_off.data(), (size_t) (S + 1) * 4);
     c->task_blob.alloc(words * sizeof(uint32_t) + 16);
-    if (n_rows) c->task_off.alloc((size_t) (S + 1) * 8 + 64);      // task offsets | gathered cell offsets + 8 counters + cell total
+    if (n_rows) c->task_off.alloc((size_t) (S + 1) * 8 + 96);      // task offsets | gathered cell offsets + 8 counters + cell total
     PDL_HIP(hipMemcpyAsync(c->task_blob.p, c->task_pin, words * sizeof(uint32_t), hipMemcpyHostToDevice, c->copy_stream));
     if (n_rows) PDL_HIP(hipMemcpyAsync(c->task_off.p, c->task_pin + words, (size_t) (S + 1) * 4, hipMemcpyHostToDevice, c->copy_stream));
     PDL_HIP(hipEventRecord(c->ev_tasks, c->copy_stream));
@@ -1418,6 +1421,8 @@ __global__ void k_iota_u32(uint32_t *dst, uint32_t n) { uint32_t i = blockIdx.x 
 // ------------------------------------------------------------------------------------------------
 struct ScorePlan {
     bool wide, mirror;
+    bool tier0;                    // the partition tier runs in front of tier 1 (short rows)
+    uint32_t grid0;
     int tier1, occ_slot;
     bool tiny_tier2;
     uint32_t grid1, grid2, grid3;
@@ -1470,6 +1475,24 @@ static ScorePlan score_plan(pdl_ctx *c) {
     if (tier1 && c->occ_tier1[pl.occ_slot] == 0) c->occ_tier1[pl.occ_slot] = occupancy(fn1, t1_threads);
     pl.grid1 = tier1 ? std::min<uint32_t>(n_rows, (uint32_t) cus * c->occ_tier1[pl.occ_slot]) : 0;
     if (c->opt_grid_pct > 0 && pl.grid1) pl.grid1 = std::max<uint32_t>(1, (uint32_t) ((uint64_t) pl.grid1 * (uint32_t) c->opt_grid_pct / 100));     // (experiments: fewer rows in flight)
+    // tier 0, the partition tier: packed ranges (gene ids below 2^22), no gene of <= 2k k-mers (single sightings are never
+    // emitted), short rows on average (a cycle takes 4096 lookups: rows of several thousand would all be handed on).
+    // "join_tier0" 1 / 0 forces it on / off; choosing the tier-1 table by hand ("join_tier1") leaves it off unless forced.
+    {
+        const unsigned long long walked = c->dist ? [&] { unsigned long long u = 0; for (uint32_t g : c->shard) u += c->h_upper_cost[g]; return u; }()
+                                          : pl.mirror ? (c->P - c->Ushared) / 2 : c->P;
+        const bool can = c->ranges8 != nullptr && !pl.wide && c->min_kseq > 2ull * c->rp.k && tier1 != 0;
+        // by itself only where it has paid on every set measured: short rows (a cycle holds 4096 lookups) of genes whose k-mers
+        // rarely repeat inside the gene — low-complexity stretches make rows wide and their lookups heavy, and such rows are handed
+        // on after the work was done (protein-like stand-in: 1.05 ms with this tier in front, 0.64 without)
+        const bool want = c->opt_tier0 > 0 || (c->opt_tier0 < 0 && c->opt_tier1 < 0 && n_rows && walked / n_rows <= 3000 && c->Urepeat * 5000 <= c->U);
+        pl.tier0 = can && want;
+        if (pl.tier0) {
+            if (c->occ_tier0 == 0) c->occ_tier0 = occupancy((const void *) k_join_part, (int) PT_T);
+            pl.grid0 = std::min<uint32_t>((n_rows + PT_BATCH - 1) / PT_BATCH, (uint32_t) cus * c->occ_tier0);
+            if (c->opt_grid_pct > 0) pl.grid0 = std::max<uint32_t>(1, (uint32_t) ((uint64_t) pl.grid0 * (uint32_t) c->opt_grid_pct / 100));
+        }
+    }
     pl.grid2 = std::min<uint32_t>(n_rows, (uint32_t) cus * (pl.tiny_tier2 ? 4 : 1));
     // tier 3: a direct-addressed table per workgroup (20 bytes per gene; 36 with 32-bit counters): as many workgroups as ~8 GB
     // of tables allow, at least 64 (configs[4]: 2 778 rows of the first genomes end up here, 0.6 ms each — 64 workgroups took
@@ -1486,7 +1509,7 @@ static ScorePlan score_plan(pdl_ctx *c) {
         c->glb_clean = true;
     }
     // Every workgroup reserves staging in chunks of CELL_CHUNK cells: a partly used chunk per workgroup of every tier
-    pl.slack = 2ull * (pl.grid1 + pl.grid2 + pl.grid3) * CELL_CHUNK;
+    pl.slack = 2ull * (pl.grid0 + pl.grid1 + pl.grid2 + pl.grid3) * CELL_CHUNK;
     return pl;
 }
 
@@ -1499,8 +1522,8 @@ static void score_alloc_rows(pdl_ctx *c, const ScorePlan &pl) {
     c->row_base.alloc((size_t) n_rows * 4); c->row_cnt.alloc((size_t) n_rows * 4); c->fin_off.alloc(((size_t) n_rows + 2) * 4);      // (+1: the scan stores its 64-bit total at [n_rows])
     c->join_ctr.alloc(64);
     c->row_desc.alloc((size_t) n_rows * sizeof(uint4));
-    c->row_desc2.alloc((size_t) n_rows * sizeof(uint4));
-    c->overflow_rows.alloc((size_t) n_rows * 4 * 2);     // list A (tier 1 -> 2) and list B (tier 2 -> 3)
+    c->row_desc2.alloc((size_t) n_rows * sizeof(uint4) * (pl.tier0 ? 2 : 1));      // descriptors of the rows a tier handed on (tier 0 -> 1 | tier 1 -> 2)
+    c->overflow_rows.alloc((size_t) n_rows * 4 * 3);     // list A (tier 1 -> 2), list B (tier 2 -> 3), list S (tier 0 -> 1)
     if (pl.mirror) c->mirror_cnt.alloc((size_t) n_rows * 4 * 3 + 16);    // counts | offsets | cursors
     c->gene_info.alloc((size_t) N * sizeof(uint4));
     hipLaunchKernelGGL(k_row_desc, dim3((std::max(n_rows, N) + 255) / 256), dim3(256), 0, c->stream, c->task_rows.as<uint32_t>(), c->seq_off.as<uint32_t>(),
@@ -1558,8 +1581,9 @@ static void score_join(pdl_ctx *c, const ScorePlan &pl) {
     }
     JoinArgs a = join_args(c, pl);
     // counters: 0 cursor tier 1 | 1 rows for tier 2 | 2 cursor tier 2 | 3 rows for tier 3 | 4-5 cell cursor | 6 errors | 7 cursor tier 3 | 9 wide rows seen by K-order
+    //           | 10 put-aside entries loaded again | 11 cursor tier 0 | 12 rows tier 0 handed to tier 1
     uint32_t *ctr32 = c->join_ctr.as<uint32_t>();
-    uint32_t *list_a = c->overflow_rows.as<uint32_t>(), *list_b = list_a + n_rows;
+    uint32_t *list_a = c->overflow_rows.as<uint32_t>(), *list_b = list_a + n_rows, *list_s = list_b + n_rows;
     a.error_count = ctr32 + 6; a.reload_count = ctr32 + 10;
     a.cell_cursor = reinterpret_cast<unsigned long long *>(ctr32 + 4);
 
@@ -1568,10 +1592,19 @@ static void score_join(pdl_ctx *c, const ScorePlan &pl) {
         hipLaunchKernelGGL(k_iota_u32, dim3((n_rows + 255) / 256), dim3(256), 0, st, list_b, n_rows);
         PDL_HIP(hipMemcpyAsync(ctr32 + 3, &c->n_task_rows, 4, hipMemcpyHostToDevice, st));
     }
-    // tier 1
+    // tier 0 (the partition tier) over every row; what it does not take is listed for tier 1
     a.work = nullptr; a.desc = c->row_desc.as<uint4>(); a.n_work = pl.wide ? 0 : n_rows; a.n_work_ptr = nullptr;
+    if (pl.tier0) {
+        a.work_cursor = ctr32 + 11; a.overflow_count = ctr32 + 12; a.overflow_rows = list_s; a.work_batch = PT_BATCH;
+        hipLaunchKernelGGL(k_join_part, dim3(pl.grid0), dim3(PT_T), 0, st, a);
+        hipLaunchKernelGGL(k_row_desc_list, dim3((n_rows + 255) / 256), dim3(256), 0, st, list_s, ctr32 + 12, c->task_rows.as<uint32_t>(),
+                           c->seq_off.as<uint32_t>(), c->row_desc2.as<uint4>() + n_rows);
+        a.desc = c->row_desc2.as<uint4>() + n_rows; a.n_work = 0; a.n_work_ptr = ctr32 + 12;
+        c->tm.join_launches += 1;
+    }
+    // tier 1
     a.work_cursor = ctr32 + 0; a.overflow_count = ctr32 + 1; a.overflow_rows = list_a;
-    a.work_batch = std::max<uint32_t>(1, std::min<uint32_t>(8, n_rows / (std::max<uint32_t>(pl.grid1, 1) * 8)));
+    a.work_batch = pl.tier0 ? 1 : std::max<uint32_t>(1, std::min<uint32_t>(8, n_rows / (std::max<uint32_t>(pl.grid1, 1) * 8)));      // (behind tier 0: few, long rows)
     if (tier1 >= 9 && tier1 <= 11) {
         // the filter tiers put a row's first sightings aside in a list per workgroup (16 bytes each; rewritten row after row, so
         // only the part in use is ever hot): room for 4x the lookups of the average row (never more than one per gene), a
@@ -1676,20 +1709,21 @@ static unsigned long long score_order(pdl_ctx *c, const ScorePlan &pl, const pdl
     // first cell of every shard genome = fin_off at its first task row; then the one look at the counters
     uint32_t *d_idx = c->task_off.as<uint32_t>();
     uint32_t *d_out = d_idx + (S + 1);
-    hipLaunchKernelGGL(k_gather_u32, dim3((S + 1 + 11 + 255) / 256), dim3(256), 0, st, c->fin_off.as<uint32_t>(), d_idx, S + 1, d_out,
+    hipLaunchKernelGGL(k_gather_u32, dim3((S + 1 + 12 + 255) / 256), dim3(256), 0, st, c->fin_off.as<uint32_t>(), d_idx, S + 1, d_out,
                        c->join_ctr.as<uint32_t>(), reinterpret_cast<const uint32_t *>(d_scal + 6));
     c->h_fin.resize(S + 1);
     uint32_t h_ctr[8];
     uint64_t zsum = 0;
     {
         PinRead rd(c);
-        const uint32_t *pf = rd.add<uint32_t>(d_out, S + 1 + 11);
+        const uint32_t *pf = rd.add<uint32_t>(d_out, S + 1 + 12);
         ev_end(c, ev_total);
         rd.sync();
         memcpy(c->h_fin.data(), pf, (size_t) (S + 1) * 4);
         memcpy(h_ctr, pf + S + 1, sizeof(h_ctr));
         memcpy(&zsum, pf + S + 1 + 8, sizeof(zsum));
         c->tm.aside_reloads = pf[S + 1 + 10];
+        c->tm.tier1_rows = pl.tier0 ? pf[S + 1 + 11] : (pl.tier1 ? n_rows : 0);
     }
     c->glb_clean = true;
     c->tm.overflow_rows = h_ctr[3];

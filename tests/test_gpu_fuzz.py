@@ -99,6 +99,7 @@ def test_mid_size_sets_under_every_join_tier_match_the_oracle(seed):
     nat = PangeneNative.open()
     nat.set_option("join_tier1", tier)
     nat.set_option("join_grid_pct", pct)
+    nat.set_option("join_tier0", int(rng.integers(0, 2)) if tier else 0)      # the partition tier in front of it, or not
     for it in range(2):
         nat.preprocess(k, gs.residues, gs.offsets, gs.genome_of)
         assert nat.cost.total_cost == ora.total_cost

@@ -254,6 +254,38 @@ def test_every_first_tier_reproduces_the_reference_digests(name, tier):
     assert tm["aside_reloads"] == 0 and tm["aside_repeats"] == 0        # the canary of the filter tiers' put-aside lists (the other tiers keep none)
 
 
+@pytest.mark.parametrize("name", H.SMALL_CASES + sorted(H.DIGESTS))
+def test_partition_tier_forced_on_reproduces_the_reference(name):
+    """The partition tier (k_join_part: several short rows per workgroup cycle, lookups partitioned by column instead of
+    hashed one by one) is chosen by the average row length; forced on ("join_tier0" 1) it must reproduce every fixture and
+    every digest of the reference — whatever it cannot take (genes of <= 2k k-mers, long rows, too many heavy lookups) it
+    hands to the filter tier."""
+    small = name in H.SMALL_CASES
+    res, off, gen, k, fx = H.load_small(name) if small else H.load_large(name)
+    nat = _native(res, off, gen, k)
+    nat.set_option("join_tier0", 1)
+    if small:
+        H.assert_scores_equal_fixture(lambda g: nat.generate_scores_part(g).as_dict(), fx, nat.cost.genomes, name)
+    else:
+        H.assert_scores_match_digest(lambda g: nat.generate_scores_part(g).as_dict(), fx, name)
+    tm = nat.timings()
+    assert tm["tier1_rows"] <= tm["scored_rows"] and tm["aside_reloads"] == 0
+    if name in ("synth_16x1000x300_k5", "synth_40x60x40_k3"):
+        assert tm["tier1_rows"] < tm["scored_rows"] // 2          # (the tier did take rows)
+
+
+@pytest.mark.parametrize("name,expect", [("synth_16x1000x300_k5", True), ("protein_like_24x1500x300_k5", False)])
+def test_partition_tier_is_taken_by_itself_only_where_it_pays(name, expect):
+    """By itself ("join_tier0" -1) the partition tier runs in front of the filter tier on short rows of genes whose k-mers
+    rarely repeat inside the gene (records with a count >= 2 at most 1 in 5000); protein-like text with low-complexity stretches
+    keeps the filter tier alone (there it costs 1.05 ms against 0.64).  Same digests either way."""
+    res, off, gen, k, d = H.load_large(name)
+    nat = _native(res, off, gen, k)
+    H.assert_scores_match_digest(lambda g: nat.generate_scores_part(g).as_dict(), d, name)
+    tm = nat.timings()
+    assert (tm["tier1_rows"] < tm["scored_rows"]) == expect
+
+
 @pytest.mark.parametrize("tier", [10, 11])
 def test_a_pass_that_saw_a_reload_is_repeated_with_fully_tagged_entries(tier):
     """The 8-byte put-aside entries carry a 10-bit tag: a stale entry passes it once in 1024.  So a pass in which any entry

@@ -12,7 +12,7 @@ gs = make_gene_set(**CONFIGS[name]); k = calculate_k(gs.residues)
 nat = PangeneNative.open()
 for o in sys.argv[2:]:
     n, v = o.split("="); nat.set_option(n, int(v))
-for it in range(2):
+for it in range(3):
     nat.preprocess(k, gs.residues, gs.offsets, gs.genome_of); nat.score_all()
 t = nat.timings()
-print({x: t[x] for x in ("scored_rows", "tier2_rows", "overflow_rows", "join_ms", "join_overflow_ms", "order_ms", "score_total_ms", "preprocess_total_ms", "emitted_cells", "aside_reloads")})
+print({x: t[x] for x in ("scored_rows", "tier1_rows", "tier2_rows", "overflow_rows", "join_ms", "join_overflow_ms", "order_ms", "score_total_ms", "preprocess_total_ms", "emitted_cells", "aside_reloads")})

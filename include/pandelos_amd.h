@@ -277,6 +277,13 @@ PDL_API int pdl_dist_score_finish(pdl_ctx *, const pdl_dist_cell *d_inbox, uint6
  * outboxes above live in library-owned memory, the exchange buffers in the caller's). */
 PDL_API int pdl_copy_device(pdl_ctx *, void *d_dst, const void *d_src, uint64_t bytes);
 
+/* Test hooks of the small device->host read protocol (a kernel stores counters straight into pinned host memory, then a
+ * checksum and an epoch flag; the host spins on both: pandelos_amd/csrc/pdl_common.h, PinRead), on plain host memory:
+ * pdl_pin_checksum = what the kernel leaves beside the flag for a payload; pdl_pin_arrived = 1 when `pin` shows `epoch` at
+ * flag_word and the words of the n segments (dst_word[s] .. + words[s]) add up to the checksum at flag_word + 1. */
+PDL_API int pdl_pin_arrived(const uint32_t *pin, const uint32_t *dst_word, const uint32_t *words, uint32_t n, uint32_t flag_word, uint32_t epoch);
+PDL_API uint32_t pdl_pin_checksum(const uint32_t *payload, const uint32_t *dst_word, const uint32_t *words, uint32_t n);
+
 /* Library/build identification, e.g. "pandelos_amd 0.1 gfx950" */
 PDL_API const char *pdl_version(void);
 

@@ -91,7 +91,7 @@ EXPORTS = ("pdl_create", "pdl_destroy", "pdl_last_error", "pdl_preprocess", "pdl
            "pdl_version", "pdl_set_option", "pdl_dist_preprocess_begin", "pdl_dist_preprocess_finish",
            "pdl_dist_genome_owner", "pdl_dist_score_begin", "pdl_dist_score_finish", "pdl_copy_device",
            "pdl_compute_edges", "pdl_free_edges", "pdl_ingest_faa", "pdl_ingest_genome_name", "pdl_preprocess_ingested",
-           "pdl_scan_faa")
+           "pdl_scan_faa", "pdl_pin_arrived", "pdl_pin_checksum")
 
 _lib = None
 
@@ -144,5 +144,7 @@ def load():
     lib.pdl_ingest_genome_name.argtypes = [vp, u32]; lib.pdl_ingest_genome_name.restype = C.c_char_p
     lib.pdl_preprocess_ingested.argtypes = [vp, i32, i32, C.POINTER(PdlCost)]; lib.pdl_preprocess_ingested.restype = i32
     lib.pdl_scan_faa.argtypes = [C.c_char_p, C.POINTER(PdlIngest), vp, u64, vp, vp, u32]; lib.pdl_scan_faa.restype = i32
+    lib.pdl_pin_arrived.argtypes = [vp, vp, vp, u32, u32, u32]; lib.pdl_pin_arrived.restype = i32
+    lib.pdl_pin_checksum.argtypes = [vp, vp, vp, u32]; lib.pdl_pin_checksum.restype = u32
     _lib = lib
     return lib

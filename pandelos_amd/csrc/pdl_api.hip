@@ -29,6 +29,17 @@ extern "C" {
 
 const char *pdl_version(void) { return "pandelos_amd 0.1 (HIP, gfx950)"; }
 
+// The host side of the small-read protocol on plain memory (no device, no context): see PinRead in pdl_common.h.
+int pdl_pin_arrived(const uint32_t *pin, const uint32_t *dst_word, const uint32_t *words, uint32_t n, uint32_t flag_word, uint32_t epoch) {
+    if (!pin || !dst_word || !words) return -1;
+    return pin_arrived(pin, dst_word, words, n, flag_word, epoch) ? 1 : 0;
+}
+uint32_t pdl_pin_checksum(const uint32_t *payload, const uint32_t *dst_word, const uint32_t *words, uint32_t n) {
+    uint32_t sum = 0, at = 0;        // payload: the segments' words one after the other, as the kernel reads them from the device
+    for (uint32_t s = 0; s < n; s++) for (uint32_t i = 0; i < words[s]; i++) sum += payload[at++] * pin_weight(dst_word[s] + i);
+    return sum;
+}
+
 pdl_ctx *pdl_create(const pdl_config *cfg) {
     pdl_ctx *c = nullptr;
     try {
@@ -46,8 +57,12 @@ pdl_ctx *pdl_create(const pdl_config *cfg) {
         if (cfg && cfg->stream) { c->stream = (hipStream_t) cfg->stream; c->own_stream = false; }
         else { PDL_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
         // (coherent = fine-grained: what a kernel stores there is visible to the host while the kernel still runs — PinRead's flag)
-        if (hipHostMalloc((void **) &c->pin, 1 << 20, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) { c->pin_bytes = 1 << 20; memset(c->pin + c->pin_bytes - PDL_PIN_FLAG_BYTES, 0, PDL_PIN_FLAG_BYTES); }
-        else { c->pin = nullptr; (void) hipGetLastError(); }
+        if (hipHostMalloc((void **) &c->pin, 1 << 20, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+            c->pin_bytes = 1 << 20; memset(c->pin + c->pin_bytes - PDL_PIN_FLAG_BYTES, 0, PDL_PIN_FLAG_BYTES);
+            void *dp = nullptr;      // kernels store into the buffer through the device's alias of it, not through the host pointer
+            if (hipHostGetDevicePointer(&dp, c->pin, 0) == hipSuccess && dp) c->pin_dev = static_cast<uint8_t *>(dp);
+            else (void) hipGetLastError();
+        } else { c->pin = nullptr; (void) hipGetLastError(); }
         return c;
     } catch (const pdl_error &e) {
         g_create_error = e.msg;

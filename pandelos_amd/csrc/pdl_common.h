@@ -264,6 +264,7 @@ struct pdl_ctx {
     pdl_timings tm{};
     EventPair ev[16];
     uint8_t *pin = nullptr;       // pinned host scratch for the small device->host reads (true async DMA, no staging copy)
+    uint8_t *pin_dev = nullptr;   // the same buffer as the device addresses it (hipHostGetDevicePointer)
     size_t pin_bytes = 0;
     uint32_t pin_epoch = 0;       // last value a k_pin_read raised the flag at the tail of `pin` to
     // host mirror of the whole scoring result (pinned): filled by ONE set of device->host copies at the first
@@ -287,13 +288,27 @@ struct PinReadArgs {
     uint32_t *pin;             // pinned host buffer as the device sees it
     uint32_t flag_word, epoch;
 };
+// The arrival checksum weights every word by its position in the WHOLE pinned buffer (odd weights: a single late word always
+// shows) — weights that restarted in every segment let two late words at the same index of different segments cancel.
+__host__ __device__ inline uint32_t pin_weight(uint32_t dst_word) { return 2u * dst_word + 1u; }
+// Host side of the protocol, on plain memory (exported for the CPU tests as pdl_pin_arrived): the flag shows this read's epoch
+// AND the words in place add up to the checksum the kernel left beside the flag.
+inline bool pin_arrived(const volatile uint32_t *pin, const uint32_t *dst_word, const uint32_t *words, uint32_t n, uint32_t flag_word, uint32_t epoch) {
+    if (pin[flag_word] != epoch) return false;
+    std::atomic_thread_fence(std::memory_order_acquire);
+    uint32_t sum = 0;
+    for (uint32_t s = 0; s < n; s++)
+        for (uint32_t i = 0; i < words[s]; i++) sum += pin[dst_word[s] + i] * pin_weight(dst_word[s] + i);
+    return sum == pin[flag_word + 1];
+}
+#ifdef __HIPCC__
 static __global__ __launch_bounds__(256) void k_pin_read(PinReadArgs a) {
     __shared__ uint32_t s_sum;
     if (threadIdx.x == 0) s_sum = 0;
     pdl_sync();
     uint32_t sum = 0;
     for (uint32_t s = 0; s < a.n; s++)
-        for (uint32_t i = threadIdx.x; i < a.words[s]; i += 256) { const uint32_t v = a.src[s][i]; a.pin[a.dst_word[s] + i] = v; sum += v * (2u * i + 1u); }
+        for (uint32_t i = threadIdx.x; i < a.words[s]; i += 256) { const uint32_t v = a.src[s][i]; a.pin[a.dst_word[s] + i] = v; sum += v * pin_weight(a.dst_word[s] + i); }
     atomicAdd(&s_sum, sum);
     __threadfence_system();
     pdl_sync();
@@ -306,6 +321,7 @@ static __global__ __launch_bounds__(256) void k_pin_read(PinReadArgs a) {
         __threadfence_system();
     }
 }
+#endif
 constexpr size_t PDL_PIN_FLAG_BYTES = 64;                    // the tail of the pinned buffer holds the flag
 struct PinRead {
     pdl_ctx *c;
@@ -340,7 +356,7 @@ struct PinRead {
         if (issued) return;
         issued = true;
         if (!k.n) return;
-        k.pin = reinterpret_cast<uint32_t *>(c->pin);
+        k.pin = reinterpret_cast<uint32_t *>(c->pin_dev ? c->pin_dev : c->pin);     // (the buffer as the device addresses it)
         k.flag_word = (uint32_t) ((c->pin_bytes - PDL_PIN_FLAG_BYTES) / 4);
         k.epoch = ++c->pin_epoch;
         hipLaunchKernelGGL(k_pin_read, dim3(1), dim3(256), 0, c->stream, k);
@@ -350,16 +366,8 @@ struct PinRead {
         issue();
         if (k.n) {
             if (!by_copy) {
-                volatile uint32_t *flag = reinterpret_cast<volatile uint32_t *>(c->pin) + k.flag_word;
                 const volatile uint32_t *words = reinterpret_cast<const volatile uint32_t *>(c->pin);
-                auto arrived = [&]() -> bool {               // flag up and every word in place (position-weighted sum, as the kernel made it)
-                    if (flag[0] != k.epoch) return false;
-                    std::atomic_thread_fence(std::memory_order_acquire);
-                    uint32_t sum = 0;
-                    for (uint32_t sgm = 0; sgm < k.n; sgm++)
-                        for (uint32_t i = 0; i < k.words[sgm]; i++) sum += words[k.dst_word[sgm] + i] * (2u * i + 1u);
-                    return sum == flag[1];
-                };
+                auto arrived = [&]() -> bool { return pin_arrived(words, k.dst_word, k.words, k.n, k.flag_word, k.epoch); };    // flag up and every word in place
                 const auto t0 = std::chrono::steady_clock::now();
                 bool ok = false;
                 for (uint32_t spins = 0; !(ok = arrived()); spins++) {

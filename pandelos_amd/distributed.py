@@ -103,6 +103,45 @@ def gather_genome_owner(shard: Sequence[int], genomes: int, device=None) -> np.n
     return mine.cpu().numpy()
 
 
+# ---- a deadline for every exchange --------------------------------------------------------------------------------
+class ExchangeDeadline:
+    """``with ExchangeDeadline(...)`` around a blocking exchange: a rank whose exchange has not completed in ``seconds`` says
+    which exchange, with which peers and how many bytes, and EXITS NON-ZERO (``os._exit``: the main thread sits inside the
+    collective and cannot be unwound; the launcher then tears the job down instead of waiting for its own limit).  A fresh
+    launch may set ``PDL_DIST_GATHER=broadcast`` to swap the point-to-point gather for broadcasts.  ``PDL_DIST_TIMEOUT_S``
+    sets the deadline (default 120 s, 0 = none)."""
+
+    EXIT_CODE = 87
+
+    def __init__(self, what: str, rank: int, world: int, detail: str = "", seconds: float = None):
+        import os
+        self.what, self.rank, self.world, self.detail = what, rank, world, detail
+        self.seconds = float(os.environ.get("PDL_DIST_TIMEOUT_S", "120")) if seconds is None else float(seconds)
+        self.timer = None
+
+    def _expired(self):
+        import os
+        import sys
+        sys.stderr.write(f"pandelos_amd: rank {self.rank} of {self.world}: exchange '{self.what}' has not completed in "
+                         f"{self.seconds:g} s ({self.detail}); giving up (exit {self.EXIT_CODE}).  "
+                         f"A fresh launch may set PDL_DIST_GATHER=broadcast for the dictionary gather.\n")
+        sys.stderr.flush()
+        os._exit(self.EXIT_CODE)
+
+    def __enter__(self):
+        if self.seconds > 0:
+            import threading
+            self.timer = threading.Timer(self.seconds, self._expired)
+            self.timer.daemon = True
+            self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self.timer is not None:
+            self.timer.cancel()
+        return False
+
+
 # ---- one rank of a torch.distributed group -----------------------------------------------------------------
 class DistributedPangenes:
     """The hot path on rank ``dist.get_rank()`` of an initialised process group.
@@ -169,16 +208,19 @@ class DistributedPangenes:
         if self.on_device:
             mine = mine.to(self.dev)
         allv = torch.empty(W * mine.numel(), dtype=torch.int64, device=mine.device)       # (flat: gloo takes no 2-D output)
-        dist.all_gather_into_tensor(allv, mine)
-        allv = allv.cpu().numpy().reshape(W, -1)
+        with ExchangeDeadline("dictionary: record counts and genome weights (all-gather)", r, W, f"{mine.numel() * 8} bytes per rank"):
+            dist.all_gather_into_tensor(allv, mine)
+            allv = allv.cpu().numpy().reshape(W, -1)
         offs = exclusive_offsets(allv[:, 0])
         weights = allv[:, 1:].sum(axis=0)
         total = int(offs[-1])
         full = torch.empty(max(total, 1), dtype=torch.int64, device=self.dev)      # 8-byte records {gene, count|flag}
         if records:
             nat.copy_device(full.data_ptr() + int(offs[r]) * 8, ptr, records * 8)
-        self._all_gather_runs(full, offs)
-        self._sync()
+        with ExchangeDeadline("dictionary: runs gathered in place (" + ("point-to-point" if self.on_device and self.p2p_gather else "broadcasts") + ")", r, W,
+                              "sending %d bytes to each peer; receiving %s bytes" % (records * 8, ", ".join(f"{int(offs[p + 1] - offs[p]) * 8} from rank {p}" for p in range(W) if p != r))):
+            self._all_gather_runs(full, offs)
+            self._sync()
         self.exchange_s["dictionary"] = time.perf_counter() - t0
         nat.dist_preprocess_finish(full.data_ptr(), total, genome_weights=weights, keepalive=full)
         return nat.cost
@@ -193,24 +235,28 @@ class DistributedPangenes:
         cdev = self.dev if self.on_device else None
         sc = torch.as_tensor(send_counts, dtype=torch.int64, device=cdev)
         rc = torch.empty(W, dtype=torch.int64, device=cdev)
-        dist.all_to_all_single(rc, sc)
-        recv_counts = rc.cpu().numpy()
+        with ExchangeDeadline("cells: counts (all-to-all)", self.rank, W, f"{W * 8} bytes"):
+            dist.all_to_all_single(rc, sc)
+            recv_counts = rc.cpu().numpy()
         n_out, n_in = int(send_counts.sum()), int(recv_counts.sum())
         send = torch.empty((max(n_out, 1), 6), dtype=torch.int32, device=self.dev)     # pdl_dist_cell = 6 x 4 bytes
         recv = torch.empty((max(n_in, 1), 6), dtype=torch.int32, device=self.dev)
         if n_out:
             nat.copy_device(send.data_ptr(), ptr, n_out * _lib.DIST_CELL_BYTES)
-        if self.on_device:
-            dist.all_to_all_single(recv[:n_in], send[:n_out], output_split_sizes=[int(x) for x in recv_counts],
-                                   input_split_sizes=[int(x) for x in send_counts])
-            self._sync()
-        else:
-            h_recv = torch.empty((n_in, 6), dtype=torch.int32)
-            dist.all_to_all_single(h_recv, send[:n_out].cpu(), output_split_sizes=[int(x) for x in recv_counts],
-                                   input_split_sizes=[int(x) for x in send_counts])
-            recv[:n_in].copy_(h_recv)
-            if self.dev.type == "cuda":
-                torch.cuda.synchronize(self.dev)
+        detail = ("sending " + ", ".join(f"{int(c) * _lib.DIST_CELL_BYTES} to rank {d}" for d, c in enumerate(send_counts) if d != self.rank) +
+                  " bytes; receiving " + ", ".join(f"{int(c) * _lib.DIST_CELL_BYTES} from rank {p}" for p, c in enumerate(recv_counts) if p != self.rank) + " bytes")
+        with ExchangeDeadline("cells: 24-byte cells (all-to-all)", self.rank, W, detail):
+            if self.on_device:
+                dist.all_to_all_single(recv[:n_in], send[:n_out], output_split_sizes=[int(x) for x in recv_counts],
+                                       input_split_sizes=[int(x) for x in send_counts])
+                self._sync()
+            else:
+                h_recv = torch.empty((n_in, 6), dtype=torch.int32)
+                dist.all_to_all_single(h_recv, send[:n_out].cpu(), output_split_sizes=[int(x) for x in recv_counts],
+                                       input_split_sizes=[int(x) for x in send_counts])
+                recv[:n_in].copy_(h_recv)
+                if self.dev.type == "cuda":
+                    torch.cuda.synchronize(self.dev)
         self.exchange_s["cells"] = time.perf_counter() - t0
         nat.dist_score_finish(recv.data_ptr(), n_in, keepalive=recv)
 

@@ -162,3 +162,45 @@ def test_driver_exchanges_runs_and_cells_in_rank_order(world, flow):
         assert d[:total] == dictionary and total == len(dictionary) and w == weights
         want = [[s, r, i, 7, 8, 9] for s in range(world) for i in range(int(fakes[s].counts[r]))]     # source-major, as all-to-all delivers
         assert inbox == want
+
+
+# ---- an exchange that does not complete ends the rank, loudly ---------------------------------------------------------
+def _deadline_worker(rank, world, port, sleeper, err_path):
+    import sys
+    import time
+    import torch
+    import torch.distributed as dist
+    sys.stderr = open(err_path, "w")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["PDL_DIST_TIMEOUT_S"] = "4"
+    os.environ.pop("PDL_DIST_GATHER", None)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    fake = _FakeRank(rank, world)
+    dp = D.DistributedPangenes(fake, torch.device("cpu"), device_collectives=True)
+    t = torch.zeros(1)
+    dp.preprocess(3, t, t, t, 1, 1)
+    if rank == sleeper:
+        time.sleep(60)                       # never reaches the cell exchange in time: the others must not wait for it for ever
+    dp.score_all()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_a_rank_whose_exchange_does_not_complete_says_which_and_exits_nonzero(tmp_path):
+    """One of two ranks sleeps in front of the cell exchange.  The other one's all-to-all cannot complete: after
+    PDL_DIST_TIMEOUT_S it names the exchange, its peers and the bytes, and exits with ExchangeDeadline.EXIT_CODE — it does not
+    hang until the launcher's own limit."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    errs = [tmp_path / f"rank{r}.err" for r in range(2)]
+    procs = [ctx.Process(target=_deadline_worker, args=(r, 2, port, 1, str(errs[r]))) for r in range(2)]
+    for p in procs:
+        p.start()
+    procs[0].join(45)
+    assert procs[0].exitcode == D.ExchangeDeadline.EXIT_CODE, procs[0].exitcode
+    text = errs[0].read_text()
+    assert "exchange 'cells: counts (all-to-all)'" in text and "rank 0 of 2" in text and "has not completed in 4 s" in text
+    procs[1].kill()
+    procs[1].join(10)

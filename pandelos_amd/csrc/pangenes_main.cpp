@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <charconv>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -81,6 +82,8 @@ int main(int argc, char **argv) {
     std::string input, output;
     int k = 0;
     bool have_k = false, complexity = false, k_auto = false;
+    std::string timings_path;      // --timings FILE (not in the reference): wall time of every stage of the pipeline, as one JSON line
+    int repeat = 1;                // --repeat N: the whole pipeline N times in this process (the first pass allocates), medians reported
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto val = [&]() -> const char * { return i + 1 < argc ? argv[++i] : nullptr; };
@@ -93,6 +96,8 @@ int main(int argc, char **argv) {
             if (v) { k_auto = strcmp(v, "auto") == 0; k = k_auto ? 0 : atoi(v); have_k = true; }      // "auto" (not in the reference): calculate_k.py's value, computed by the ingest pass
         }
         else if (a == "-j" || a == "--threads") { (void) val(); }
+        else if (a == "--timings") { const char *v = val(); if (v) timings_path = v; }
+        else if (a == "--repeat") { const char *v = val(); if (v) repeat = std::max(1, atoi(v)); }
         else { input.clear(); break; }
     }
     if (input.empty() || output.empty() || !have_k) {           // Cli.java:83-87
@@ -104,6 +109,15 @@ int main(int argc, char **argv) {
     // ---- PangeneIData.readFromFile: the library's streaming ingest (pdl_ingest.hip) — the file goes to HBM as it is parsed ----
     pdl_ctx *ctx = pdl_create(nullptr);
     if (!ctx) { fprintf(stderr, "pandelos_amd: %s\n", pdl_last_error(nullptr)); return 1; }
+    using clk = std::chrono::steady_clock;
+    auto ms_since = [](clk::time_point t) { return std::chrono::duration<double, std::milli>(clk::now() - t).count(); };
+    std::vector<std::vector<double>> stage(6);       // ingest | dictionary | scores | edges | net (container + text) | all
+    uint64_t n_edges_total = 0, file_bytes = 0, n_cells = 0;
+    uint32_t n_genes = 0, n_genomes = 0;
+  for (int pass = 0; pass < repeat; pass++) {
+    const bool quiet = pass > 0;
+    const auto t_all = clk::now();
+    auto t0 = clk::now();
     pdl_ingest ing;
     if (pdl_ingest_faa(ctx, input.c_str(), &ing) != PDL_OK) {
         // Pangenes.java:26-31: the reader's exception is printed and main returns
@@ -111,35 +125,56 @@ int main(int argc, char **argv) {
         pdl_destroy(ctx);
         return 0;
     }
+    stage[0].push_back(ms_since(t0));
+    file_bytes = ing.file_bytes; n_genes = ing.sequences; n_genomes = ing.genomes;
     const uint32_t G = ing.genomes;
-    if (k_auto) { k = ing.k_suggested; printf("k = %d\n", k); }                // calculate_k.py:30 (the line pandelos.sh:67-68 greps for)
+    if (k_auto) { k = ing.k_suggested; if (!quiet) printf("k = %d\n", k); }                // calculate_k.py:30 (the line pandelos.sh:67-68 greps for)
     if (k <= 0) { printf("K value must be greater than 0."); return 1; }      // library.cpp:90-93
+    t0 = clk::now();
     pdl_cost cost;
     if (pdl_preprocess_ingested(ctx, k, complexity ? 1 : 0, &cost) != PDL_OK) {
         fprintf(stderr, "pandelos_amd: %s\n", pdl_last_error(ctx));
         return 1;
     }
-    if (cost.hash_fallback) printf("Hashing fallback!\n");
-    printf("------------\nCOMPUTATIONAL COSTS: \nTotal cost: %llu lookups\nLinear ratio: %g\n------------\n\n",
-           (unsigned long long) cost.total_cost, (double) cost.linear_ratio);
+    stage[1].push_back(ms_since(t0));
+    if (!quiet) {
+        if (cost.hash_fallback) printf("Hashing fallback!\n");
+        printf("------------\nCOMPUTATIONAL COSTS: \nTotal cost: %llu lookups\nLinear ratio: %g\n------------\n\n",
+               (unsigned long long) cost.total_cost, (double) cost.linear_ratio);
+    }
     if (complexity) { pdl_destroy(ctx); return 0; }                           // Pangenes.java:33-36
 
     // ---- per-genome tasks, Pangenes.java:60-183 ------------------------------------------------------------
     // The best-hit filter of the task (:98-176) runs on the device, over the cells where they are (pdl_compute_edges,
     // pdl_bbh.hip); what arrives here are the task's addConnection calls in order.
+    t0 = clk::now();
+    if (pdl_score_all(ctx) != PDL_OK) { fprintf(stderr, "pandelos_amd: %s\n", pdl_last_error(ctx)); return 1; }
+    stage[2].push_back(ms_since(t0));
+    t0 = clk::now();
     Net net;
     std::vector<uint32_t> counts(G, 0);
     if (pdl_scores_counts(ctx, counts.data()) != PDL_OK) { fprintf(stderr, "pandelos_amd: %s\n", pdl_last_error(ctx)); return 1; }
+    n_cells = 0;
+    for (uint32_t g = 0; g < G; g++) n_cells += counts[g];
+    std::vector<pdl_edges> per_genome(G);
+    uint64_t n_edges = 0;
     for (uint32_t g = 0; g < G; g++) {
-        pdl_edges e;
-        if (pdl_compute_edges(ctx, g, &e) != PDL_OK) { fprintf(stderr, "pandelos_amd: %s\n", pdl_last_error(ctx)); return 1; }
-        uint64_t gcost = 0;
-        (void) pdl_genome_cost(ctx, g, &gcost);
-        printf("Genome %u cost = %llu\nFiltered count: %u\n", g, (unsigned long long) gcost, counts[g]);   // library.cpp:535-538, Pangenes.java:68
+        if (pdl_compute_edges(ctx, g, &per_genome[g]) != PDL_OK) { fprintf(stderr, "pandelos_amd: %s\n", pdl_last_error(ctx)); return 1; }
+        n_edges += per_genome[g].count;
+    }
+    stage[3].push_back(ms_since(t0));
+    n_edges_total = n_edges;
+    t0 = clk::now();
+    for (uint32_t g = 0; g < G; g++) {
+        pdl_edges &e = per_genome[g];
+        if (!quiet) {
+            uint64_t gcost = 0;
+            (void) pdl_genome_cost(ctx, g, &gcost);
+            printf("Genome %u cost = %llu\nFiltered count: %u\n", g, (unsigned long long) gcost, counts[g]);   // library.cpp:535-538, Pangenes.java:68
+        }
         for (uint32_t i = 0; i < e.count; i++) net.add(e.src[i], e.dst[i], e.score[i]);
         pdl_free_edges(&e);
     }
-    pdl_destroy(ctx);
 
     // ---- PangeneNet.saveToFile(file, false) ---------------------------------------------------------------
     size_t cap = 16;
@@ -148,7 +183,7 @@ int main(int argc, char **argv) {
     for (size_t i = 0; i < order.size(); i++) order[i] = i;
     auto bucket = [&](int32_t key) { const uint32_t h = (uint32_t) key; return (size_t) ((h ^ (h >> 16)) & (uint32_t) (cap - 1)); };
     std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return bucket(net.keys[x]) < bucket(net.keys[y]); });
-    printf("----------\nwriting into %s\n", output.c_str());
+    if (!quiet) printf("----------\nwriting into %s\n", output.c_str());
     FILE *f = fopen(output.c_str(), "w");
     if (!f) { perror(output.c_str()); return 0; }
     for (size_t oi : order) {
@@ -157,5 +192,20 @@ int main(int argc, char **argv) {
             if (src <= e.first) fprintf(f, "%d\t%d\t%s\n", src, e.first, java_double((double) e.second).c_str());
     }
     fclose(f);
+    stage[4].push_back(ms_since(t0));
+    stage[5].push_back(ms_since(t_all));
+  }
+    pdl_destroy(ctx);
+    if (!timings_path.empty()) {
+        auto median = [](std::vector<double> v) { if (v.size() > 1) v.erase(v.begin()); std::sort(v.begin(), v.end()); return v[v.size() / 2]; };   // (first pass allocates: left out when there are more)
+        FILE *t = fopen(timings_path.c_str(), "w");
+        if (t) {
+            fprintf(t, "{\"passes\": %d, \"file_bytes\": %llu, \"genes\": %u, \"genomes\": %u, \"cells\": %llu, \"edges_added\": %llu, "
+                       "\"faa_to_hbm_ms\": %.4f, \"dictionary_ms\": %.4f, \"scores_ms\": %.4f, \"bbh_edges_to_host_ms\": %.4f, \"net_ms\": %.4f, \"faa_to_net_ms\": %.4f}\n",
+                    repeat, (unsigned long long) file_bytes, n_genes, n_genomes, (unsigned long long) n_cells, (unsigned long long) n_edges_total,
+                    median(stage[0]), median(stage[1]), median(stage[2]), median(stage[3]), median(stage[4]), median(stage[5]));
+            fclose(t);
+        }
+    }
     return 0;
 }

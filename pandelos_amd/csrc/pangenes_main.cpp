@@ -20,6 +20,7 @@
 #include <cstring>
 #include <limits>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -63,11 +64,12 @@ struct Net {
     std::vector<float> score;
     void add(int32_t s, int32_t d, float sc) { src.push_back(s); dst.push_back(d); score.push_back(sc); }
 
-    // -> the text of saveToFile(file, false)
-    std::string text() const {
+    // -> the text of saveToFile(file, false), in pieces that follow each other (one per host thread: the sources in map order
+    //    are cut into stretches, every thread formats its own)
+    std::vector<std::string> text(unsigned threads = 8) const {
         const size_t E = src.size();
-        std::string out;
-        if (!E) return out;
+        std::vector<std::string> pieces;
+        if (!E) return pieces;
         int32_t max_id = 0;
         for (size_t i = 0; i < E; i++) max_id = std::max(max_id, std::max(src[i], dst[i]));
         const size_t N = (size_t) max_id + 1;
@@ -91,30 +93,41 @@ struct Net {
         for (size_t b = 0; b < cap; b++) bcnt[b + 1] += bcnt[b];
         std::vector<int32_t> ordered(keys.size());
         for (int32_t k : keys) ordered[bcnt[bucket(k)]++] = k;           // (keys are visited in insertion order: stable)
-        out.reserve(E * 16);
-        std::vector<std::pair<int32_t, uint32_t>> seg;                   // {destination, edge} of one source
-        char buf[64];
-        for (int32_t s_id : ordered) {
-            seg.clear();
-            for (uint32_t q = cnt[s_id]; q < cnt[s_id + 1]; q++) seg.emplace_back(dst[by_src[q]], by_src[q]);
-            std::stable_sort(seg.begin(), seg.end(), [](const auto &x, const auto &y) { return x.first < y.first; });   // (a handful per source)
-            for (size_t q = 0; q < seg.size(); q++) {
-                if (q && seg[q].first == seg[q - 1].first) continue;     // TreeSet keyed by destination: the first insert stays
-                if (s_id > seg[q].first) continue;                       // undirected save
-                auto r = std::to_chars(buf, buf + sizeof(buf), s_id);
-                out.append(buf, r.ptr); out.push_back('\t');
-                r = std::to_chars(buf, buf + sizeof(buf), seg[q].first);
-                out.append(buf, r.ptr); out.push_back('\t');
-                const double x = (double) score[seg[q].second];
-                if (x >= 1e-3 && x < 1e7) {                              // Double.toString's plain decimal range: shortest round-trip digits, at least one after the point
-                    r = std::to_chars(buf, buf + sizeof(buf), x, std::chars_format::fixed);
-                    out.append(buf, r.ptr);
-                    if (!memchr(buf, '.', (size_t) (r.ptr - buf))) out.append(".0");
-                } else out.append(java_double(x));
-                out.push_back('\n');
+        const unsigned T = (unsigned) std::max<size_t>(1, std::min<size_t>(threads, ordered.size() / 4096 + 1));
+        pieces.resize(T);
+        auto format = [&](unsigned t) {
+            std::string &out = pieces[t];
+            const size_t k0 = ordered.size() * t / T, k1 = ordered.size() * (t + 1) / T;
+            out.reserve((size_t) ((double) E / T * 20));
+            std::vector<std::pair<int32_t, uint32_t>> seg;               // {destination, edge} of one source
+            char buf[64];
+            for (size_t ki = k0; ki < k1; ki++) {
+                const int32_t s_id = ordered[ki];
+                seg.clear();
+                for (uint32_t q = cnt[s_id]; q < cnt[s_id + 1]; q++) seg.emplace_back(dst[by_src[q]], by_src[q]);
+                std::stable_sort(seg.begin(), seg.end(), [](const auto &x, const auto &y) { return x.first < y.first; });   // (a handful per source)
+                for (size_t q = 0; q < seg.size(); q++) {
+                    if (q && seg[q].first == seg[q - 1].first) continue;     // TreeSet keyed by destination: the first insert stays
+                    if (s_id > seg[q].first) continue;                       // undirected save
+                    auto r = std::to_chars(buf, buf + sizeof(buf), s_id);
+                    out.append(buf, r.ptr); out.push_back('\t');
+                    r = std::to_chars(buf, buf + sizeof(buf), seg[q].first);
+                    out.append(buf, r.ptr); out.push_back('\t');
+                    const double x = (double) score[seg[q].second];
+                    if (x >= 1e-3 && x < 1e7) {                              // Double.toString's plain decimal range: shortest round-trip digits, at least one after the point
+                        r = std::to_chars(buf, buf + sizeof(buf), x, std::chars_format::fixed);
+                        out.append(buf, r.ptr);
+                        if (!memchr(buf, '.', (size_t) (r.ptr - buf))) out.append(".0");
+                    } else out.append(java_double(x));
+                    out.push_back('\n');
+                }
             }
-        }
-        return out;
+        };
+        std::vector<std::thread> team;
+        for (unsigned t = 1; t < T; t++) team.emplace_back(format, t);
+        format(0);
+        for (auto &th : team) th.join();
+        return pieces;
     }
 };
 
@@ -217,6 +230,7 @@ int main(int argc, char **argv) {
     stage[3].push_back(ms_since(t0));
     n_edges_total = n_edges;
     t0 = clk::now();
+    net.src.reserve(n_edges); net.dst.reserve(n_edges); net.score.reserve(n_edges);
     for (uint32_t g = 0; g < G; g++) {
         pdl_edges &e = per_genome[g];
         if (!quiet) {
@@ -230,10 +244,10 @@ int main(int argc, char **argv) {
 
     // ---- PangeneNet.saveToFile(file, false) ---------------------------------------------------------------
     if (!quiet) printf("----------\nwriting into %s\n", output.c_str());
-    const std::string text = net.text();
+    const std::vector<std::string> text = net.text();
     FILE *f = fopen(output.c_str(), "w");
     if (!f) { perror(output.c_str()); return 0; }
-    fwrite(text.data(), 1, text.size(), f);
+    for (const std::string &piece : text) fwrite(piece.data(), 1, piece.size(), f);
     fclose(f);
     stage[4].push_back(ms_since(t0));
     stage[5].push_back(ms_since(t_all));

@@ -145,7 +145,8 @@ struct pdl_ctx {
 
     // K-ingest (pdl_ingest.hip): the input a .faa file was parsed into, and the two pinned staging buffers it travelled through
     DevBuf ing_res, ing_off, ing_gen;
-    uint8_t *ing_pin[2] = {nullptr, nullptr};
+    uint8_t *ing_pin[2] = {nullptr, nullptr};    // [0]: the pinned staging buffer of the ingest (the whole file's residues)
+    size_t ing_pin_bytes = 0;
     hipEvent_t ing_ev[2] = {nullptr, nullptr};
     hipStream_t ing_stream = nullptr;
     std::vector<uint64_t> ing_h_off;

@@ -82,6 +82,66 @@ def test_scan_k_of_the_stand_in_sets(name, tmp_path):
     assert np.array_equal(s["residues"], gs.residues) and np.array_equal(s["offsets"], gs.offsets) and np.array_equal(s["genome_of"], gs.genome_of)
 
 
+def _messy_faa(seed, records, genomes=9):
+    """A few MB of .faa text with everything the reader's rules are about, spread over the whole file (so that every chunk of
+    the parallel parse starts in a different state): all three terminators, blank and whitespace-only lines between and INSIDE
+    records (the raw line parity calculate_k.py goes by drifts away from the header / sequence alternation), padding to trim,
+    genomes that come back after others, letters that first appear late."""
+    rng = np.random.default_rng(seed)
+    out = []
+    term = [b"\n", b"\r\n", b"\r"]
+    letters = b"ACDEFGHIKLMNPQRSTVWY"
+    for i in range(records):
+        g = int(rng.integers(0, min(genomes, 2 + i * genomes // max(records // 2, 1))))
+        pad = [b"", b" ", b"\t ", b"\x01"][int(rng.integers(0, 4))]
+        out += [pad, b"genome_%d\tgene_%d\tproduct %d" % (g, i, i), pad, term[int(rng.integers(0, 3))]]
+        while rng.random() < 0.1:
+            out += [[b"", b"  ", b"\t"][int(rng.integers(0, 3))], term[int(rng.integers(0, 3))]]
+        n = int(rng.integers(1, 400))
+        seq = bytes(letters[int(x)] for x in rng.integers(0, 20 if i > records // 3 else 12, n))
+        if i == records - 7:
+            seq += b"XBZ"                              # letters seen for the first time near the end
+        out += [pad, seq, pad, term[int(rng.integers(0, 3))]]
+        while rng.random() < 0.1:
+            out += [[b"", b" "][int(rng.integers(0, 2))], term[int(rng.integers(0, 3))]]
+    text = b"".join(out)
+    return text[:-1] if seed % 2 and text.endswith(b"\n") else text     # (sometimes no terminator at the very end)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_parallel_scan_of_a_messy_file_equals_the_reader(seed, tmp_path):
+    """Files of several MB are cut into chunks at line starts and parsed by a team of threads (pdl_ingest.hip): same sequences,
+    offsets, genome ids in first-seen order and k as the one-pass reader that mirrors the Java, whatever state a chunk starts in."""
+    p = tmp_path / "messy.faa"
+    text = _messy_faa(seed, 14000 + 1000 * seed)
+    assert len(text) > 2 * (1 << 20)
+    p.write_bytes(text)
+    s = _same(p)
+    # calculate_k.py opens the file in text mode: universal newlines, the same raw lines
+    assert s["k_suggested"] == calculate_k_faa(p)
+    assert s["genomes"] == 9
+
+
+def test_parallel_scan_reports_the_first_malformed_header(tmp_path):
+    import ctypes as C
+    lib = _lib.load()
+    text = _messy_faa(7, 15000)
+    lines = text.split(b"\n")
+    # break two headers far apart (both behind the first chunk): the one the one-pass reader meets first is reported
+    hdr = [i for i, l in enumerate(lines) if l.strip(b" \t\x01\r").startswith(b"genome_") and b"\r" not in l.strip(b"\r")]
+    a, b = hdr[len(hdr) // 2], hdr[-5]
+    for i in (a, b):
+        lines[i] = lines[i].replace(b"\tproduct", b" product")
+    p = tmp_path / "bad.faa"
+    p.write_bytes(b"\n".join(lines))
+    ing = _lib.PdlIngest()
+    assert lib.pdl_scan_faa(str(p).encode(), C.byref(ing), None, 0, None, None, 0) == _lib.PDL_ERR_ARGUMENT
+    msg = lib.pdl_last_error(None).decode()
+    with open(p, "r") as f:                            # raw line number as the reader counts (universal newlines)
+        want = next(n for n, l in enumerate(f, 1) if l.strip(" \t\x01\n").startswith("genome_") and l.count("\t") - l.strip(" \t\x01\n").count("\t") >= 0 and l.strip(" \t\x01\n").count("\t") < 2)
+    assert f"line {want}:" in msg, msg
+
+
 def test_scan_errors(tmp_path):
     import ctypes as C
     lib = _lib.load()

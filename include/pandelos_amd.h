@@ -107,6 +107,8 @@ typedef struct {
     uint32_t aside_repeats;        /* scoring passes thrown away and repeated with fully tagged (16-byte) list entries because a pass with
                                       the 10-bit tags saw a reload: no result is ever returned from such a pass */
     uint32_t tier1_rows;           /* rows that reached the filtered small-table tier (all of them unless the partition tier ran in front) */
+    float reshard_ms;              /* the range lists built again for another genome shard on the existing dictionary (pdl_set_genome_shard after pdl_preprocess) */
+    uint32_t reserved1;
 } pdl_timings;
 
 PDL_API pdl_ctx *pdl_create(const pdl_config *cfg /* may be NULL */);
@@ -165,9 +167,13 @@ PDL_API int pdl_sequence_costs(const pdl_ctx *, uint64_t *out_total_visited /* [
  * posting-range lists, per-gene costs and pdl_cost.total_cost are then built for the shard's genes only
  * (the part of the dictionary build that is proportional to the rows scored).  Without a shard the
  * range lists hold only the genes above each row and every cell is produced once for both of its rows, so
- * a dictionary built for all genomes cannot score a subset (PDL_ERR_STATE); a dictionary built for a shard
- * can be narrowed further.  count == 0 clears the shard.  The shard stays in force across
- * pdl_preprocess calls. */
+ * a dictionary built for all genomes cannot score a subset (PDL_ERR_STATE).  A dictionary built for a shard can be
+ * narrowed further — or pointed at ANOTHER shard: the postings stay, the range lists of the new shard's genes are built
+ * before the next scoring pass (two passes over the postings; pdl_timings.reshard_ms).  That is how a set too large for one
+ * device's memory is scored a batch of genomes at a time (the reference's unit of work, Pangenes.java:60-66, with the
+ * reference's per-task scratch, library.cpp:417-428): shard = batch 0, pdl_preprocess, fetch the batch's Scores, shard =
+ * batch 1, fetch, ... — only one batch's maxima, staging and cells are on the device at a time (option "low_memory" also
+ * returns the build's transient buffers).  count == 0 clears the shard.  The shard stays in force across pdl_preprocess calls. */
 PDL_API int pdl_set_genome_shard(pdl_ctx *, const uint32_t *genomes, uint32_t count);
 
 /* computeScores for every genome of the shard in one device pass (library.cpp:409-527 for each
@@ -215,7 +221,9 @@ PDL_API int pdl_get_timings(pdl_ctx *, pdl_timings *out);
  * tier of the join launched with n % of the workgroups the chip holds, 0 = all: an experiment knob — how the join scales
  * with rows in flight), "stage_timers" 0|1 (default 1: HIP events around every stage fill the stage
  * fields of pdl_timings; 0: only the totals and the join's launch time are taken — each event pair is two marker packets
- * between dispatches, a few microseconds of idle stream on a two-millisecond step), "aside_test_reload" 0|1 (test switch: the next scoring pass
+ * between dispatches, a few microseconds of idle stream on a two-millisecond step), "low_memory" 0|1 (for genome batches on a large set: the buffers only the dictionary build needed are released after it —
+ * pdl_get_dictionary is then not available — and tier 3's tables in HBM take 1 GB instead of 8), "onepass_scan" 0|1 (prefix scans
+ * in one launch with decoupled look-back instead of three launches; measured slower on MI355X, default 0), "aside_test_reload" 0|1 (test switch: the next scoring pass
  * behaves as if an entry of a put-aside list had needed a second look, so the repeat with fully tagged entries runs). */
 PDL_API int pdl_set_option(pdl_ctx *, const char *name, int64_t value);
 

@@ -55,7 +55,7 @@ class PdlTimings(C.Structure):
                 ("tier2_rows", C.c_uint32),
                 ("dist_begin_ms", C.c_float), ("dist_finish_ms", C.c_float), ("dist_score_begin_ms", C.c_float),
                 ("dist_score_finish_ms", C.c_float), ("walked_lookups", C.c_uint64), ("outbox_cells", C.c_uint64),
-                ("inbox_cells", C.c_uint64), ("aside_reloads", C.c_uint64), ("aside_repeats", C.c_uint32), ("tier1_rows", C.c_uint32)]
+                ("inbox_cells", C.c_uint64), ("aside_reloads", C.c_uint64), ("aside_repeats", C.c_uint32), ("tier1_rows", C.c_uint32), ("reshard_ms", C.c_float), ("reserved1", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if not n.startswith("reserved")}

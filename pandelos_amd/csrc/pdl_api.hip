@@ -147,7 +147,7 @@ void pdl_set_create_error(const std::string &msg) { g_create_error = msg; }
 int pdl_preprocess_common(pdl_ctx *c, uint32_t n, uint64_t n_res, int k, int only_complexity, pdl_cost *out_cost) {
     PDL_GUARD_BEGIN
     PDL_HIP(hipSetDevice(c->device));
-    c->preprocessed = false; c->scored = false; c->tasks_ready = false;      // the genome shard, if one was set, stays in force
+    c->preprocessed = false; c->scored = false; c->tasks_ready = false; c->reshard_pending = false;      // the genome shard, if one was set, stays in force
     c->N = n; c->R = n_res;
     c->U = c->Ushared = c->NG = c->P = c->M = 0;
     if (k <= 0) PDL_FAIL(PDL_ERR_KVALUE, "K value must be greater than 0.");
@@ -294,15 +294,16 @@ int pdl_set_genome_shard(pdl_ctx *c, const uint32_t *genomes, uint32_t count) {
         c->err = "genome shard: set it before pdl_preprocess (the dictionary on the device was built for all genomes)";
         return PDL_ERR_STATE;
     }
+    bool rebuild = false;
     if (c->preprocessed && !c->dict_shard.empty()) {
-        // the dictionary on the device only has range lists for the genes of dict_shard
+        // the dictionary on the device only has range lists for the genes of dict_shard: another shard gets its own before the next
+        // scoring pass (the postings stay: two passes over them, pdl_run_reshard) — how a large set is scored a batch of genomes at a time
+        if (count == 0) { c->err = "genome shard: the dictionary was built for a shard; run pdl_preprocess again to widen it to all genomes"; return PDL_ERR_STATE; }
         for (uint32_t g : s)
-            if (!std::binary_search(c->dict_shard.begin(), c->dict_shard.end(), g)) {
-                c->err = "genome shard: not a subset of the shard the dictionary was built for; run pdl_preprocess again";
-                return PDL_ERR_STATE;
-            }
-        if (count == 0) { c->err = "genome shard: the dictionary was built for a shard; run pdl_preprocess again to widen it"; return PDL_ERR_STATE; }
+            if (!std::binary_search(c->dict_shard.begin(), c->dict_shard.end(), g)) rebuild = true;
+        if (rebuild && (c->only_complexity || !c->head_bits.p)) { c->err = "genome shard: not a subset of the shard the dictionary was built for; run pdl_preprocess again"; return PDL_ERR_STATE; }
     }
+    c->reshard_pending = c->reshard_pending || rebuild;
     c->shard = std::move(s);
     c->shard_set = count != 0;
     c->scored = false;
@@ -318,6 +319,7 @@ static int score_all_locked(pdl_ctx *c) {
     if (c->dist) PDL_FAIL(PDL_ERR_STATE, "multi-GPU context: score with pdl_dist_score_begin / pdl_dist_score_finish");
     PDL_HIP(hipSetDevice(c->device));
     c->mirror_valid = false; c->edges_valid = false;
+    if (c->reshard_pending) { pdl_run_reshard(c); c->reshard_pending = false; }
     pdl_run_score_all(c);
     return PDL_OK;
     PDL_GUARD_END(c)
@@ -540,6 +542,8 @@ int pdl_set_option(pdl_ctx *c, const char *name, int64_t value) {
     else if (n == "host_mirror") c->opt_host_mirror = value != 0;
     else if (n == "staging_cap") c->opt_staging_cap = value > 0 ? (uint64_t) value : 0;
     else if (n == "aside_test_reload") c->opt_aside_test_reload = value != 0;
+    else if (n == "onepass_scan") c->opt_onepass_scan = value != 0;
+    else if (n == "low_memory") c->opt_low_memory = value != 0;
     else { c->err = "unknown option " + n; return PDL_ERR_ARGUMENT; }
     c->scored = false;        // the next scoring call runs with the new setting
     return PDL_OK;
@@ -641,6 +645,7 @@ int pdl_get_dictionary(pdl_ctx *c, uint64_t *ranks, uint32_t *seqs, uint32_t *co
     PDL_GUARD_BEGIN
     if (!c->preprocessed) PDL_FAIL(PDL_ERR_STATE, "pdl_get_dictionary before pdl_preprocess");
     if (c->dist) PDL_FAIL(PDL_ERR_STATE, "pdl_get_dictionary: a multi-GPU context keeps ranks only for its own interval");
+    if (!c->keys_b.p || !c->recpos.p) PDL_FAIL(PDL_ERR_STATE, "pdl_get_dictionary: the sorted k-mer stream was released (option low_memory)");
     PDL_HIP(hipSetDevice(c->device));
     const uint64_t U = c->U, M = c->M;
     std::vector<uint32_t> recpos(U);

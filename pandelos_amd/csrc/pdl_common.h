@@ -173,6 +173,11 @@ struct pdl_ctx {
     DevBuf seq_off;       // u32 [N+1] range list of each gene
     bool upper_only = false;  // ranges hold only the columns above the row: the join mirrors every cell
     DevBuf scan_tmp;      // block sums of the scans
+    DevBuf lb_tile, lb_chunk, lb_ctr;     // decoupled look-back (pdl_scan.h): status words of tiles / chunks, ticket + arrival counters
+    uint32_t lb_epoch = 0;
+    bool opt_low_memory = false;          // batches of genomes on a large set: build buffers released after the dictionary, small HBM tables for tier 3
+    bool reshard_pending = false;         // pdl_set_genome_shard named genomes the range lists on the device do not cover: they are built before the next scoring pass
+    bool opt_onepass_scan = false;        // scans in one launch (decoupled look-back) instead of three: measured 3-10 % slower per scan on MI355X, kept as an option
     DevBuf scratch;       // transient buffers of the range build
     DevBuf scalars;       // control block, u64: totals [16] | residue histogram [256] | per-genome cost [G] (PDL_CTL_*)
 
@@ -385,6 +390,7 @@ struct PinRead {
 
 // stage entry points (pdl_dict.hip / pdl_join.hip)
 void pdl_run_preprocess(pdl_ctx *c, int kvalue, bool only_complexity);
+void pdl_run_reshard(pdl_ctx *c);       // the range lists again, for the genomes of c->shard, on the dictionary that is there
 void pdl_run_dist_begin(pdl_ctx *c, int kvalue);
 void pdl_run_dist_finish(pdl_ctx *c, uint64_t total_records, const uint64_t *genome_weights);
 void pdl_run_score_all(pdl_ctx *c);

@@ -1231,16 +1231,27 @@ static void stage_ranges_and_costs(pdl_ctx *c, uint64_t bound, int mode, bool on
         // range sits right behind its own record (the upper modes) and a posting count fits 22 bits; else as 16-byte
         // tuples fetched through the sorted positions.
         const bool packed = mode != 0 && c->N < (1u << 22);
-        // scratch: packed   pay_a u64[bound] | pay_b u64[bound] | k2b u32[bound]
-        //          tuples   tuples uint4[bound] | v2a u32[bound] | k2b u32[bound] | v2b u32[bound];   key2 lives in vals_a (free after sort 1)
-        c->scratch.alloc(bound * (packed ? 2 * sizeof(uint64_t) + sizeof(uint32_t) : sizeof(uint4) + 3 * sizeof(uint32_t)));
-        c->vals_a.alloc(bound * sizeof(uint32_t));
-        uint4 *tuples = c->scratch.as<uint4>();
-        unsigned long long *pay_a = c->scratch.as<unsigned long long>(), *pay_b = pay_a + bound;
-        uint32_t *k2a = c->vals_a.as<uint32_t>();
-        uint32_t *v2a = packed ? nullptr : reinterpret_cast<uint32_t *>(tuples + bound);
-        uint32_t *k2b = packed ? reinterpret_cast<uint32_t *>(pay_b + bound) : v2a + bound;
-        uint32_t *v2b = packed ? nullptr : k2b + bound;
+        // scratch: packed   pay_a u64[cap] | pay_b u64[cap] | k2b u32[cap]
+        //          tuples   tuples uint4[cap] | v2a u32[cap] | k2b u32[cap] | v2b u32[cap];   key2 lives in vals_a (free after sort 1) or behind them
+        // cap = the bound (every record may get a range) when the whole build stays on the device without a look from the host
+        // (mode 1); with a shard (modes 0, 2: 1/W or one batch of the genes) the COUNT pass's total is read first and the buffers
+        // are sized for it — a 512-genome set would otherwise allocate 20-28 bytes for each of its 0.9 G records per shard
+        const bool exact = mode != 1;
+        uint64_t cap = bound;
+        uint4 *tuples = nullptr;
+        unsigned long long *pay_a = nullptr, *pay_b = nullptr;
+        uint32_t *k2a = nullptr, *v2a = nullptr, *k2b = nullptr, *v2b = nullptr;
+        auto carve = [&]() {
+            c->scratch.alloc(cap * (packed ? 2 * sizeof(uint64_t) + sizeof(uint32_t) : sizeof(uint4) + 3 * sizeof(uint32_t)) + (exact ? cap * sizeof(uint32_t) : 0) + 64);
+            tuples = c->scratch.as<uint4>();
+            pay_a = c->scratch.as<unsigned long long>(); pay_b = pay_a + cap;
+            v2a = packed ? nullptr : reinterpret_cast<uint32_t *>(tuples + cap);
+            k2b = packed ? reinterpret_cast<uint32_t *>(pay_b + cap) : v2a + cap;
+            v2b = packed ? nullptr : k2b + cap;
+            if (exact) k2a = (packed ? k2b : v2b) + cap;                     // (the sort's first buffer may be gone: "low_memory")
+            else { c->vals_a.alloc(cap * sizeof(uint32_t)); k2a = c->vals_a.as<uint32_t>(); }
+        };
+        if (!exact) carve();
         if (mode != 1) {                    // the shard as gene-id intervals, when every genome's genes are consecutive ids (the usual .faa)
             std::vector<uint2> &iv = c->h_own_iv;
             iv.clear();
@@ -1272,12 +1283,10 @@ static void stage_ranges_and_costs(pdl_ctx *c, uint64_t bound, int mode, bool on
             PDL_HIP(hipMemcpyAsync(c->seq_in_shard.p, h.data(), c->N, hipMemcpyHostToDevice, st));
             ga.in_shard = c->seq_in_shard.as<uint8_t>();
         }
-        ga.key2 = k2a; ga.tuples = tuples;
-        if (packed) {
-            ga.pay8 = pay_a;
-            c->head_bits.alloc(((bound + GW_TILE - 1) / GW_TILE) * GW_ROUNDS * sizeof(uint64_t));
-            ga.head_bits = c->head_bits.as<unsigned long long>();
-        }
+        // the head bits the WRITE pass takes out of the postings are kept: for the per-gene costs made on demand (packed ranges), and
+        // to put them back when the ranges are built again for another shard of genomes (pdl_run_reshard)
+        c->head_bits.alloc(((bound + GW_TILE - 1) / GW_TILE) * GW_ROUNDS * sizeof(uint64_t));
+        ga.head_bits = c->head_bits.as<unsigned long long>();
         const uint64_t *d_us = d_scal + 2;       // ranges built = the total of the tile counts
         // single-GPU build with packed ranges: the tuples are filed by the low byte of their gene by the kernel that makes
         // them (the first pass of the gene sort without a trip through HBM in between)
@@ -1304,6 +1313,15 @@ static void stage_ranges_and_costs(pdl_ctx *c, uint64_t bound, int mode, bool on
         }
         hipLaunchKernelGGL(k_tile_prefix, dim3((ga.n_blocks + 3) / 4), dim3(256), 0, st, ga.tile_sums, ga.d_n, ga.n_bound, ga.chunk_sums, ga.n_blocks);
         hipLaunchKernelGGL(k_scan_tile_scan, dim3(1), dim3(1024), 0, st, ga.chunk_sums, ga.n_blocks, d_scal + 2, (uint64_t *) nullptr);
+        if (exact) {                         // the shard's range count, then buffers of that size
+            if (!c->tasks_ready) pdl_prepare_tasks(c);       // host work + small uploads while the device counts
+            PinRead rd(c);
+            const uint64_t *pn = rd.add<uint64_t>(d_us, 1);
+            rd.sync();
+            cap = std::max<uint64_t>(pn[0], 1);
+            carve();
+        }
+        ga.key2 = k2a; ga.tuples = tuples; ga.pay8 = packed ? pay_a : nullptr;
         if (mode == 1) launch_group_tiles<1, 1, false, false>(c, ga, grid);
         else if (mode == 2) launch_group_tiles<1, 2, false, false>(c, ga, grid);
         else launch_group_tiles<1, 0, false, false>(c, ga, grid);
@@ -1314,13 +1332,7 @@ static void stage_ranges_and_costs(pdl_ctx *c, uint64_t bound, int mode, bool on
         // builds ranges for 1/world of the records, so it reads the count (one synchronisation) and sizes them exactly.
         uint64_t n_sort = bound;
         const uint64_t *d_sort_n = d_us;
-        if (c->dist) {
-            if (!c->tasks_ready) pdl_prepare_tasks(c);       // host work + small uploads while the device runs the two passes
-            PinRead rd(c);
-            const uint64_t *pn = rd.add<uint64_t>(d_us, 1);
-            rd.sync();
-            n_sort = pn[0]; d_sort_n = nullptr;
-        }
+        if (exact) { n_sort = cap; d_sort_n = nullptr; }
         c->seq_off.alloc(((size_t) c->N + 1) * sizeof(uint32_t));
         if (packed) {
             if (fused) {                     // pass 1 is done: (k2b, pay_b) hold its output, the remaining passes go on from there
@@ -1358,7 +1370,9 @@ static void stage_ranges_and_costs(pdl_ctx *c, uint64_t bound, int mode, bool on
     {
         PinRead rd(c);                       // one copy: the whole control block
         const uint64_t *pt = rd.add<uint64_t>(d_scal, PDL_CTL_GCOST + (size_t) c->G);
+        const uint32_t *lbe = lookback_error_word(c, rd);
         rd.sync();
+        lookback_check(c, lbe);
         c->h_genome_cost.assign(pt + PDL_CTL_GCOST, pt + PDL_CTL_GCOST + c->G);     // (a shard, one rank of several: its own genomes only)
         memcpy(tail, pt, sizeof(tail));
         tail_own = pt[12]; tail_rep = pt[13];
@@ -1373,6 +1387,44 @@ static void stage_ranges_and_costs(pdl_ctx *c, uint64_t bound, int mode, bool on
     c->P = 0;
     if (c->costs_ready) for (uint64_t v : c->h_genome_cost) c->P += v;
     else c->P = tail_own;                     // packed ranges: "Total cost" straight from the WRITE pass; per-gene / per-genome costs on demand
+}
+
+// ---- the ranges again, for another shard of genomes, on the dictionary that is there ---------------------------------------------
+// (scoring a large set a batch of genomes at a time: the postings — rank, sort, dedup, most of the build — are made once; a batch
+// costs the two passes over the postings that form its genes' range lists.)  The WRITE pass took the group-head bits out of the
+// postings; they are put back from the copy it kept, the counters of the range stage start at zero again.
+__global__ __launch_bounds__(256) void k_restore_heads(uint2 *__restrict__ post, const unsigned long long *__restrict__ head_bits, uint32_t n) {
+    const uint32_t u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= n) return;
+    if ((head_bits[u >> 6] >> (u & 63u)) & 1ull) post[u].y |= HEAD_BIT;          // (word layout: record >> 6, see k_gene_costs_lazy)
+}
+
+void pdl_run_reshard(pdl_ctx *c) {
+    hipStream_t st = c->stream;
+    if (c->dist || c->post_ext) PDL_FAIL(PDL_ERR_STATE, "genome shard: a multi-GPU context deals the genomes itself");
+    if (c->dict_shard.empty() || c->upper_only) PDL_FAIL(PDL_ERR_STATE, "genome shard: the dictionary was built for all genomes; set the first shard before pdl_preprocess");
+    uint64_t *d_scal = c->scalars.as<uint64_t>();
+    const uint32_t n = (uint32_t) c->U;
+    ev_begin(c, EV_PRE_TOTAL);
+    hipLaunchKernelGGL(k_restore_heads, dim3((n + 255) / 256), dim3(256), 0, st, c->post.as<uint2>(), c->head_bits.as<unsigned long long>(), n);
+    PDL_HIP(hipMemsetAsync(d_scal + 2, 0, sizeof(uint64_t), st));
+    PDL_HIP(hipMemsetAsync(d_scal + 10, 0, 6 * sizeof(uint64_t), st));
+    PDL_HIP(hipMemsetAsync(d_scal + PDL_CTL_GCOST, 0, 2 * (size_t) c->G * sizeof(uint64_t), st));
+    PDL_HIP(hipMemsetAsync(c->cost.p, 0, (size_t) c->N * sizeof(uint64_t), st));
+    // (k_genome_cost adds the k-mer statistics of all genes up once more: they are taken from the first build)
+    const uint64_t sum_kseq = c->sum_kseq, max_kseq = c->max_kseq, min_kseq = c->min_kseq;
+    PDL_HIP(hipMemsetAsync(d_scal + 4, 0, sizeof(uint64_t), st));
+    PDL_HIP(hipMemsetAsync(d_scal + 7, 0, 2 * sizeof(uint64_t), st));
+    c->dict_shard = c->shard;
+    c->tasks_ready = false;
+    ev_begin(c, EV_DICT); ev_end(c, EV_DICT);
+    stage_ranges_and_costs(c, c->U, 0, false);
+    c->sum_kseq = sum_kseq; c->max_kseq = max_kseq; c->min_kseq = min_kseq;
+    ev_end(c, EV_PRE_TOTAL);
+    PDL_HIP(hipStreamSynchronize(st));
+    c->tm.sort_seq_ms = ev_ms(c, EV_SORT2);
+    c->tm.ranges_ms = ev_ms(c, EV_RANGES);
+    c->tm.reshard_ms = ev_ms(c, EV_PRE_TOTAL);
 }
 
 // cost[] (per gene) and h_genome_cost (per genome), when the build left them for later (packed ranges)
@@ -1413,6 +1465,11 @@ static void dictionary_pipeline(pdl_ctx *c, bool only_complexity) {
     // U (records) and the range count stay on the device until the end of the build: everything below is sized and
     // launched for the bound M and reads the counts there — no host round trip in the middle of the pipeline
     stage_ranges_and_costs(c, M, c->dict_shard.empty() ? 1 : 0, only_complexity);
+    if (c->opt_low_memory) {                 // what only the build needed goes back (the sorted k-mer stream with it: pdl_get_dictionary is not available then)
+        PDL_HIP(hipStreamSynchronize(c->stream));
+        c->keys_a.release(); c->keys_b.release(); c->vals_a.release(); c->vals_b.release(); c->recpos.release(); c->sort_tmp.release();
+        if (c->ranges8 == nullptr) {}        // (packed ranges live in `scratch`: it stays)
+    }
 }
 
 void pdl_run_preprocess(pdl_ctx *c, int kvalue, bool only_complexity) {

@@ -1499,7 +1499,7 @@ static ScorePlan score_plan(pdl_ctx *c) {
     // 26.7 ms over them)
     {
         const unsigned long long per_wg = (unsigned long long) std::max<uint32_t>(N, 1) * ((pl.wide ? 2 : 1) * sizeof(uint64_t) + 3 * sizeof(uint32_t));
-        const unsigned long long fit = (8ull << 30) / per_wg;
+        const unsigned long long fit = ((c->opt_low_memory ? 1ull : 8ull) << 30) / per_wg;
         pl.grid3 = (uint32_t) std::min<unsigned long long>((unsigned long long) cus, std::max<unsigned long long>(64, fit));
     }
     const size_t hbm_bytes = (size_t) pl.grid3 * N * ((pl.wide ? 2 : 1) * sizeof(uint64_t) + 3 * sizeof(uint32_t));
@@ -1717,8 +1717,10 @@ static unsigned long long score_order(pdl_ctx *c, const ScorePlan &pl, const pdl
     {
         PinRead rd(c);
         const uint32_t *pf = rd.add<uint32_t>(d_out, S + 1 + 12);
+        const uint32_t *lbe = lookback_error_word(c, rd);
         ev_end(c, ev_total);
         rd.sync();
+        lookback_check(c, lbe);
         memcpy(c->h_fin.data(), pf, (size_t) (S + 1) * 4);
         memcpy(h_ctr, pf + S + 1, sizeof(h_ctr));
         memcpy(&zsum, pf + S + 1 + 8, sizeof(zsum));

@@ -217,6 +217,25 @@ class PangeneNative:
         g = np.ascontiguousarray(genomes, dtype=np.uint32)
         self._check(self._lib.pdl_set_genome_shard(self._ctx, g.ctypes.data, len(g)))
 
+    def scores_in_batches(self, k, residues, offsets, genome_of, genomes_per_batch: int, low_memory: bool = True):
+        """Score a set a batch of genomes at a time and yield ``(genome, Scores)`` for every genome in ascending order — for sets
+        whose maxima, staging and cells do not fit the device together (the reference's own granularity: one task per genome
+        with private scratch, Pangenes.java:60-66, library.cpp:417-428).  The dictionary is built once, with the first batch as
+        the genome shard; every further batch costs the two passes over the postings that form its genes' range lists
+        (``pdl_set_genome_shard`` on an existing dictionary).  Batches are scored without the row/column symmetry of the
+        whole-set pass (a cell's mirror belongs to another batch), i.e. with the reference's full lookup count."""
+        gen = np.ascontiguousarray(genome_of, dtype=np.uint32)
+        n_genomes = int(gen.max()) + 1 if len(gen) else 0
+        if low_memory:
+            self.set_option("low_memory", 1)
+        for g0 in range(0, n_genomes, max(1, int(genomes_per_batch))):
+            batch = list(range(g0, min(n_genomes, g0 + max(1, int(genomes_per_batch)))))
+            self.set_genome_shard(batch)
+            if g0 == 0:
+                self.preprocess(k, residues, offsets, gen)
+            for g in batch:
+                yield g, self.generate_scores_part(g)
+
     def genome_cost(self, genome: int) -> int:
         v = C.c_uint64()
         self._check(self._lib.pdl_genome_cost(self._ctx, genome, C.byref(v)))

@@ -148,3 +148,33 @@ def test_eight_ranks_give_the_same_digests_as_one_gpu(state):
     assert rt.total_cost == state["total_cost"]
     assert 2 * int(rt.outbox_counts.sum()) > 0
     rt.nat.close()
+
+
+def test_batches_of_64_genomes_stay_under_64_gb_and_give_the_same_digests(state):
+    """The memory ceiling of the whole-set pass (maxima for every (row, genome), staging, cells and their mirrors resident:
+    ~150 GB here) is not the path's: scored a batch of 64 genomes at a time on one dictionary (pdl_set_genome_shard on the
+    existing dictionary, option low_memory) the set peaks under 64 GB of HBM and every genome's Scores block has the digest
+    of the whole-set pass — with the reference's full lookup count, no row/column symmetry across batches."""
+    if state["digests"] is None:
+        pytest.skip("the default-tier run did not complete")
+    import gc
+    import torch
+    from pandelos_amd.pangene_native import PangeneNative
+    gs, k = state["gs"], state["k"]
+    gc.collect(); torch.cuda.empty_cache()
+    free0, total = torch.cuda.mem_get_info(0)
+    nat = PangeneNative.open()
+    peak, seen, lookups = 0, 0, 0
+    for g, s in nat.scores_in_batches(k, gs.residues, gs.offsets, gs.genome_of, 64):
+        assert _digest(s.as_dict()) == state["digests"][g], f"genome {g} (batches of 64) differs from the whole-set pass"
+        seen += 1
+        if g % 64 == 0:
+            peak = max(peak, free0 - torch.cuda.mem_get_info(0)[0])
+            tm = nat.timings()
+            assert tm["aside_reloads"] == 0 and tm["walked_lookups"] == tm["scored_lookups"]      # (no symmetry inside a batch)
+            lookups += tm["scored_lookups"]
+    peak = max(peak, free0 - torch.cuda.mem_get_info(0)[0])
+    assert seen == gs.genomes and lookups == state["total_cost"]
+    assert peak <= 64 * 2 ** 30, f"peak device memory of the batched run: {peak / 2 ** 30:.1f} GiB"
+    print(f"configs[4] in batches of 64 genomes: peak {peak / 2 ** 30:.1f} GiB of HBM")
+    nat.close()

@@ -353,8 +353,17 @@ def test_shard_set_before_preprocess_builds_only_its_rows():
             got = nat.generate_scores_part(g).as_dict()
             for f in H.FIELDS:
                 assert np.array_equal(H.raw(got[f]), fx[f"g{g}_{f}"]), (g, f)
+        # another shard on the same dictionary — wider, or disjoint: its range lists are built before the next scoring pass
+        for other in ([0, 1, 2, 3, 4], [g for g in range(5) if g not in shard]):
+            nat.set_genome_shard(other)
+            for g in other:
+                got = nat.generate_scores_part(g).as_dict()
+                for f in H.FIELDS:
+                    assert np.array_equal(H.raw(got[f]), fx[f"g{g}_{f}"]), (g, f)
+                assert nat.genome_cost(g) == int(fx["genome_cost"][g])
+            assert nat.timings()["reshard_ms"] > 0
         with pytest.raises(_lib.PdlError):
-            nat.set_genome_shard([0, 1, 2, 3, 4])       # wider than what the dictionary was built for
+            nat.set_genome_shard([])                    # back to "all genomes, symmetric pass": that is another dictionary build
     assert total == int(fx["total_cost"])
 
 
@@ -437,3 +446,30 @@ def test_gene_with_over_a_million_kmers_uses_wide_counters():
     for g in range(4):
         H.assert_scores_equal(nat.generate_scores_part(g).as_dict(), ora.scores(g), f"genome {g}")
     assert nat.timings()["overflow_rows"] == len(genes)
+
+
+@pytest.mark.parametrize("name,per_batch", [("synth_16x1000x300_k5", 5), ("protein_like_24x1500x300_k5", 7), ("synth_40x60x40_k3", 40), ("synth_40x60x40_k3", 1)])
+def test_genome_batches_on_one_dictionary_reproduce_the_reference_digests(name, per_batch):
+    """A set scored a batch of genomes at a time (pdl_set_genome_shard on an existing dictionary: the postings are built once,
+    each batch gets its own range lists; option low_memory) gives every genome the Scores block of the whole-set pass — the
+    reference's digests — although no batch sees the row/column symmetry the whole-set pass uses."""
+    from pandelos_amd.pangene_native import PangeneNative
+    res, off, gen, k, d = H.load_large(name)
+    nat = PangeneNative.open()
+    got = {}
+    reshards = 0
+    for g, s in nat.scores_in_batches(k, res, off, gen, per_batch):
+        got[g] = s.as_dict()
+        reshards += nat.timings()["reshard_ms"] > 0 and g % per_batch == 0
+    assert sorted(got) == list(range(d["genomes"]))
+    H.assert_scores_match_digest(lambda g: got[g], d, f"{name} in batches of {per_batch}")
+    assert [nat.genome_cost(g) for g in range(d["genomes"] - 1, d["genomes"])] == d["genome_cost"][-1:]      # (the last batch's costs are on the context)
+    assert reshards == (d["genomes"] - 1) // per_batch
+    with pytest.raises(_lib_error()):
+        nat.dictionary()                                # low_memory: the sorted k-mer stream went back after the build
+    nat.close()
+
+
+def _lib_error():
+    from pandelos_amd import _lib
+    return _lib.PdlError

@@ -750,8 +750,12 @@ __global__ __launch_bounds__(GW_THREADS) void k_range_count(GroupTileArgs a) {
             bool r = MODE == 0 ? shared : (live && !next_head);
             if constexpr (MODE == 0 || MODE == 2) r = r && ((ins >> j) & 1u);
             cnt += r;
-            n_rec += shared; n_grp += head && !next_head; n_rep += live && (po[j].y & ~HEAD_BIT) >= 2u;
+            n_rec += shared; n_grp += head && !next_head;
             if (head) { first_h = min(first_h, u); last_h = max(last_h, u); any_h = 1; }
+        }
+        if ((tile & 7u) == 0) {                          // (uniform) records whose k-mer repeats inside its gene: a statistic, taken from every eighth tile
+#pragma unroll
+            for (int j = 0; j < GW_ROUNDS; j++) n_rep += 8u * (uint32_t) (t0 + j * PDL_WAVE + lane < n && (po[j].y & ~HEAD_BIT) >= 2u);
         }
 #pragma unroll
         for (int d = PDL_WAVE / 2; d > 0; d >>= 1) {
@@ -807,7 +811,7 @@ __global__ __launch_bounds__(GW_THREADS) void k_range_count_hist(GroupTileArgs a
                 const bool r = live && !next_head;
                 if (r) atomicAdd(&s_h[po[j].x & (PDL_RADIX_BINS - 1)], 1u);
                 cnt += r;
-                n_rec += live && !(head && next_head); n_grp += head && !next_head; n_rep += live && (po[j].y & ~HEAD_BIT) >= 2u;
+                n_rec += live && !(head && next_head); n_grp += head && !next_head;
                 if (head) { first_h = min(first_h, u); last_h = max(last_h, u); any_h = 1; }
             }
 #pragma unroll
@@ -818,6 +822,10 @@ __global__ __launch_bounds__(GW_THREADS) void k_range_count_hist(GroupTileArgs a
                 any_h |= (uint32_t) __shfl_xor((int) any_h, d, PDL_WAVE);
             }
             if (lane == 0) { a.tile_sums[tile] = cnt; a.th_first[tile] = first_h; a.th_last[tile] = any_h ? last_h : GT_NONE; }
+            if ((tile & 7u) == 0) {                      // (uniform) records whose k-mer repeats inside its gene: a statistic, taken from every eighth tile
+#pragma unroll
+                for (int j = 0; j < GW_ROUNDS; j++) n_rep += 8u * (uint32_t) (t0 + j * PDL_WAVE + lane < n && (po[j].y & ~HEAD_BIT) >= 2u);
+            }
         }
         pdl_sync();
         counts[(size_t) tid * n_tiles4 + blk] = s_h[tid];

@@ -13,7 +13,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/pf --output-format csv -- pyth
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/pw --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-scale-set --no-host-path --no-traffic > $out/pw.log 2>&1 || exit 1
 python3 tools/pmc_traffic.py $out/pf $out/pw mycoplasma64_standin "$tag" > $out/${tag}b_pmc_traffic_join.json; rm -rf $out/pf $out/pw
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA --kernel-trace -d $out/pa --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-scale-set --no-host-path --no-traffic > $out/pa.log 2>&1 || exit 1
-python3 tools/pmc_summary.py $out/pa k_join_lds > $out/${tag}_pmc_sq_cycles_join.json; rm -rf $out/pa
+python3 tools/pmc_summary.py $out/pa k_join > $out/${tag}_pmc_sq_cycles_join.json; rm -rf $out/pa
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_INSTS_SMEM --kernel-trace -d $out/pb --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-scale-set --no-host-path --no-traffic > $out/pb.log 2>&1 || exit 1
-python3 tools/pmc_summary.py $out/pb k_join_lds > $out/${tag}_pmc_sq_insts_join.json; rm -rf $out/pb
+python3 tools/pmc_summary.py $out/pb k_join > $out/${tag}_pmc_sq_insts_join.json; rm -rf $out/pb
 tail -c 600 $out/${tag}_bench_default.json

@@ -1485,7 +1485,7 @@ static ScorePlan score_plan(pdl_ctx *c) {
         // by itself only where it has paid on every set measured: short rows (a cycle holds 4096 lookups) of genes whose k-mers
         // rarely repeat inside the gene — low-complexity stretches make rows wide and their lookups heavy, and such rows are handed
         // on after the work was done (protein-like stand-in: 1.05 ms with this tier in front, 0.64 without)
-        const bool want = c->opt_tier0 > 0 || (c->opt_tier0 < 0 && c->opt_tier1 < 0 && n_rows && walked / n_rows <= 3000 && c->Urepeat * 5000 <= c->U);
+        const bool want = c->opt_tier0 > 0 || (c->opt_tier0 < 0 && c->opt_tier1 < 0 && n_rows >= 12288 && walked / n_rows <= 3000 && c->Urepeat * 5000 <= c->U);      // (fewer rows: the extra launches cost more than the tier saves)
         pl.tier0 = can && want;
         if (pl.tier0) {
             if (c->occ_tier0 == 0) c->occ_tier0 = occupancy((const void *) k_join_part, (int) PT_T);

@@ -128,7 +128,7 @@ def main():
             ranks_info.append({"rank": r, "genomes": int((owner == r).sum()), "run_records": runs[r][0], "run_kmers": runs[r][1],
                                "rows": int(tm["scored_rows"]), "walked_lookups": int(tm["walked_lookups"]), "join_ms": tm["join_ms"],
                                "sort_rank_ms": tm["sort_rank_ms"], "rank_ms": tm["rank_ms"], "sort_seq_ms": tm["sort_seq_ms"], "ranges_ms": tm["ranges_ms"],
-                               "outbox_cells": n_out})
+                               "outbox_cells": n_out, "aside_repeats": int(tm["aside_repeats"]), "aside_reloads": int(tm["aside_reloads"]), "tier1_rows": int(tm["tier1_rows"])})
         cmat = np.stack(out_counts)                  # [src][dst]
         # ---- pass 3: score_finish (+ check) -------------------------------------------------------------------------------
         sfinish_ms = []

@@ -149,6 +149,8 @@ int main(int argc, char **argv) {
     bool have_k = false, complexity = false, k_auto = false;
     std::string timings_path;      // --timings FILE (not in the reference): wall time of every stage of the pipeline, as one JSON line
     int repeat = 1;                // --repeat N: the whole pipeline N times in this process (the first pass allocates), medians reported
+    int genome_batch = 0;          // --genome-batch N (not in the reference): score N genomes at a time on one dictionary — sets whose maxima,
+                                   // staging and cells do not fit the device together (pdl_set_genome_shard on an existing dictionary)
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto val = [&]() -> const char * { return i + 1 < argc ? argv[++i] : nullptr; };
@@ -163,6 +165,7 @@ int main(int argc, char **argv) {
         else if (a == "-j" || a == "--threads") { (void) val(); }
         else if (a == "--timings") { const char *v = val(); if (v) timings_path = v; }
         else if (a == "--repeat") { const char *v = val(); if (v) repeat = std::max(1, atoi(v)); }
+        else if (a == "--genome-batch") { const char *v = val(); if (v) genome_batch = std::max(0, atoi(v)); }
         else { input.clear(); break; }
     }
     if (input.empty() || output.empty() || !have_k) {           // Cli.java:83-87
@@ -197,6 +200,16 @@ int main(int argc, char **argv) {
     if (k <= 0) { printf("K value must be greater than 0."); return 1; }      // library.cpp:90-93
     t0 = clk::now();
     pdl_cost cost;
+    const bool batched = genome_batch > 0 && (uint32_t) genome_batch < G && !complexity;
+    auto set_batch = [&](uint32_t g0) {
+        std::vector<uint32_t> ids;
+        for (uint32_t g = g0; g < std::min<uint32_t>(G, g0 + (uint32_t) genome_batch); g++) ids.push_back(g);
+        return pdl_set_genome_shard(ctx, ids.data(), (uint32_t) ids.size());
+    };
+    if (batched) {
+        (void) pdl_set_option(ctx, "low_memory", 1);
+        if (set_batch(0) != PDL_OK) { fprintf(stderr, "pandelos_amd: %s\n", pdl_last_error(ctx)); return 1; }
+    }
     if (pdl_preprocess_ingested(ctx, k, complexity ? 1 : 0, &cost) != PDL_OK) {
         fprintf(stderr, "pandelos_amd: %s\n", pdl_last_error(ctx));
         return 1;
@@ -204,8 +217,9 @@ int main(int argc, char **argv) {
     stage[1].push_back(ms_since(t0));
     if (!quiet) {
         if (cost.hash_fallback) printf("Hashing fallback!\n");
-        printf("------------\nCOMPUTATIONAL COSTS: \nTotal cost: %llu lookups\nLinear ratio: %g\n------------\n\n",
-               (unsigned long long) cost.total_cost, (double) cost.linear_ratio);
+        if (batched) printf("------------\nCOMPUTATIONAL COSTS: \n(genome batches of %d: the lookups are counted batch by batch)\n------------\n\n", genome_batch);
+        else printf("------------\nCOMPUTATIONAL COSTS: \nTotal cost: %llu lookups\nLinear ratio: %g\n------------\n\n",
+                    (unsigned long long) cost.total_cost, (double) cost.linear_ratio);
     }
     if (complexity) { pdl_destroy(ctx); return 0; }                           // Pangenes.java:33-36
 
@@ -217,15 +231,21 @@ int main(int argc, char **argv) {
     stage[2].push_back(ms_since(t0));
     t0 = clk::now();
     Net net;
-    std::vector<uint32_t> counts(G, 0);
-    if (pdl_scores_counts(ctx, counts.data()) != PDL_OK) { fprintf(stderr, "pandelos_amd: %s\n", pdl_last_error(ctx)); return 1; }
-    n_cells = 0;
-    for (uint32_t g = 0; g < G; g++) n_cells += counts[g];
+    std::vector<uint32_t> counts(G, 0), bcounts(G, 0);
+    std::vector<uint64_t> gcosts(G, 0);
     std::vector<pdl_edges> per_genome(G);
     uint64_t n_edges = 0;
-    for (uint32_t g = 0; g < G; g++) {
-        if (pdl_compute_edges(ctx, g, &per_genome[g]) != PDL_OK) { fprintf(stderr, "pandelos_amd: %s\n", pdl_last_error(ctx)); return 1; }
-        n_edges += per_genome[g].count;
+    n_cells = 0;
+    for (uint32_t g0 = 0; g0 < G; g0 += batched ? (uint32_t) genome_batch : G) {
+        const uint32_t g1 = batched ? std::min<uint32_t>(G, g0 + (uint32_t) genome_batch) : G;
+        if (batched && g0 && set_batch(g0) != PDL_OK) { fprintf(stderr, "pandelos_amd: %s\n", pdl_last_error(ctx)); return 1; }      // (its range lists are built before it is scored)
+        if (pdl_scores_counts(ctx, bcounts.data()) != PDL_OK) { fprintf(stderr, "pandelos_amd: %s\n", pdl_last_error(ctx)); return 1; }
+        for (uint32_t g = g0; g < g1; g++) {
+            counts[g] = bcounts[g]; n_cells += counts[g];
+            if (pdl_compute_edges(ctx, g, &per_genome[g]) != PDL_OK) { fprintf(stderr, "pandelos_amd: %s\n", pdl_last_error(ctx)); return 1; }
+            n_edges += per_genome[g].count;
+            (void) pdl_genome_cost(ctx, g, &gcosts[g]);
+        }
     }
     stage[3].push_back(ms_since(t0));
     n_edges_total = n_edges;
@@ -233,11 +253,7 @@ int main(int argc, char **argv) {
     net.src.reserve(n_edges); net.dst.reserve(n_edges); net.score.reserve(n_edges);
     for (uint32_t g = 0; g < G; g++) {
         pdl_edges &e = per_genome[g];
-        if (!quiet) {
-            uint64_t gcost = 0;
-            (void) pdl_genome_cost(ctx, g, &gcost);
-            printf("Genome %u cost = %llu\nFiltered count: %u\n", g, (unsigned long long) gcost, counts[g]);   // library.cpp:535-538, Pangenes.java:68
-        }
+        if (!quiet) printf("Genome %u cost = %llu\nFiltered count: %u\n", g, (unsigned long long) gcosts[g], counts[g]);   // library.cpp:535-538, Pangenes.java:68
         for (uint32_t i = 0; i < e.count; i++) net.add(e.src[i], e.dst[i], e.score[i]);
         pdl_free_edges(&e);
     }

@@ -112,6 +112,25 @@ def test_native_host_binary_writes_the_fixture_net(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("per_batch", [3, 1])
+def test_native_host_in_genome_batches_writes_the_same_net(per_batch, tmp_path):
+    """--genome-batch N: the genomes scored N at a time on one dictionary (for sets whose results do not fit the device
+    together); a genome's task — its Scores block, the best-hit filter over it — does not depend on the batch it is in, so
+    the .net is the fixture's, byte for byte."""
+    from pandelos_amd import _lib
+    name = "synth_8x300x200_k4_div25"
+    shape, k = CASES[name]
+    gs = make_gene_set(**shape)
+    faa, net = tmp_path / "in.faa", tmp_path / "out.net"
+    gs.write_faa(faa)
+    p = subprocess.run([str(_lib.LIB_DIR / "pangenes"), "-i", str(faa), "-k", str(k), "-o", str(net), "--genome-batch", str(per_batch)],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    assert net.read_text() == (NET / f"{name}.net").read_text()
+    assert "genome batches of" in p.stdout and p.stdout.count("Filtered count:") == shape["genomes"]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["synth_5x60x80_k3", "paralogs_6x80x120_k3"])
 def test_wrapper_script_goes_from_faa_to_the_fixture_clus(name, tmp_path):
     """pandelos_mi355x.sh <in.faa> <prefix>: k selection, the native stage on the GPU, de-clustering — without a PanDelos

@@ -274,6 +274,26 @@ def test_partition_tier_forced_on_reproduces_the_reference(name):
         assert tm["tier1_rows"] < tm["scored_rows"] // 2          # (the tier did take rows)
 
 
+@pytest.mark.parametrize("name", H.SMALL_CASES + sorted(H.DIGESTS))
+def test_scans_in_one_launch_reproduce_the_reference(name):
+    """"onepass_scan" 1: every prefix scan of the build and of the scoring pass is ONE launch (two-level decoupled look-back,
+    k_scan_onepass in pdl_scan.h) instead of tile sums + scan of the sums + apply.  Off by default (measured slower on MI355X);
+    it must reproduce every fixture and digest all the same, twice in a row on one context (the epoch of the look-back words
+    moves on), and no look-back may have run into its poll bound (the host would have failed the call)."""
+    from pandelos_amd.pangene_native import PangeneNative
+    small = name in H.SMALL_CASES
+    res, off, gen, k, fx = H.load_small(name) if small else H.load_large(name)
+    nat = PangeneNative.open()
+    nat.set_option("onepass_scan", 1)
+    for _ in range(2):
+        nat.preprocess(k, res, off, gen)
+        if small:
+            H.assert_scores_equal_fixture(lambda g: nat.generate_scores_part(g).as_dict(), fx, nat.cost.genomes, name)
+        else:
+            H.assert_scores_match_digest(lambda g: nat.generate_scores_part(g).as_dict(), fx, name)
+    nat.close()
+
+
 @pytest.mark.parametrize("name,expect", [("synth_16x1000x300_k5", True), ("protein_like_24x1500x300_k5", False)])
 def test_partition_tier_is_taken_by_itself_only_where_it_pays(name, expect):
     """By itself ("join_tier0" -1) the partition tier runs in front of the filter tier on short rows of genes whose k-mers

@@ -191,7 +191,7 @@ class Runner:
         self.step()
         self.sync()
         t0 = time.perf_counter()
-        join_ms, pre_ms, score_ms, xd, xc = [], [], [], [], []
+        join_ms, pre_ms, score_ms, xd, xc, xr = [], [], [], [], [], []
         for _ in range(steps):
             self.step()
             ts = self.nat.timings_struct()           # (HIP-event times of this step's launches; three fields, no dictionary: the loop is timed)
@@ -199,7 +199,7 @@ class Runner:
             pre_ms.append(ts.preprocess_total_ms)
             score_ms.append(ts.score_total_ms)
             if self.dp is not None:
-                xd.append(self.dp.exchange_s["dictionary"] * 1e3); xc.append(self.dp.exchange_s["cells"] * 1e3)
+                xd.append(self.dp.exchange_s["dictionary"] * 1e3); xc.append(self.dp.exchange_s["cells"] * 1e3); xr.append(self.dp.exchange_s["ranges"] * 1e3)
         self.sync()
         elapsed = D.all_reduce_max(time.perf_counter() - t0, device=coll_dev)
         sec_per_step = elapsed / max(steps, 1)
@@ -222,8 +222,9 @@ class Runner:
                  "join": tm["join_ms"], "join_overflow": tm["join_overflow_ms"], "order": tm["order_ms"],
                  "tier1_rows": tm["tier1_rows"], "tier2_rows": tm["tier2_rows"], "overflow_rows": tm["overflow_rows"], "aside_reloads": tm["aside_reloads"]}
         if self.dp is not None:
-            stage.update({"dist_begin": tm["dist_begin_ms"], "dist_finish": tm["dist_finish_ms"], "dist_score_begin": tm["dist_score_begin_ms"],
-                          "dist_score_finish": tm["dist_score_finish_ms"], "exchange_dictionary_wall": mean(xd), "exchange_cells_wall": mean(xc),
+            stage.update({"dist_begin": tm["dist_begin_ms"], "dist_ranges": tm["dist_ranges_ms"], "dist_finish": tm["dist_finish_ms"], "dist_score_begin": tm["dist_score_begin_ms"],
+                          "dist_score_finish": tm["dist_score_finish_ms"], "range_lists_by": "senders" if self.dp.sender_ranges else "owners",
+                          "exchange_dictionary_wall": mean(xd), "exchange_ranges_wall": mean(xr), "exchange_cells_wall": mean(xc),
                           "outbox_cells_rank0": tm["outbox_cells"]})
         return {"pairs": pairs, "sec_per_step": sec_per_step, "cost": cost, "stage_ms": stage, "join_bytes": join_bytes, "join_s": join_s,
                 "bytes_alg_total": bytes_alg_total, "z_total": z_total, "p_total": p_total, "walked": walked}

@@ -108,7 +108,7 @@ typedef struct {
                                       the 10-bit tags saw a reload: no result is ever returned from such a pass */
     uint32_t tier1_rows;           /* rows that reached the filtered small-table tier (all of them unless the partition tier ran in front) */
     float reshard_ms;              /* the range lists built again for another genome shard on the existing dictionary (pdl_set_genome_shard after pdl_preprocess) */
-    uint32_t reserved1;
+    float dist_ranges_ms;          /* pdl_dist_preprocess_ranges, device time (0 when the owners build the range lists) */
 } pdl_timings;
 
 PDL_API pdl_ctx *pdl_create(const pdl_config *cfg /* may be NULL */);
@@ -260,7 +260,33 @@ typedef struct {
     const uint64_t *genome_weights; /* host, [genomes]: every genome's lookups above the diagonal inside this run; summed over
                                  the ranks they are the weights of the genome deal; valid until the next call on this context */
     uint32_t genomes;
+    const uint64_t *genome_costs;   /* host, [genomes]: every genome's lookups inside this run as the reference counts them (library.cpp:327);
+                                 summed over the ranks: "Genome g cost" (exact whenever pdl_dist_preprocess_ranges says "available") */
 } pdl_dist_slice;
+
+/* Range lists built by the senders (the default flow of pandelos_amd/distributed.py).  pdl_dist_preprocess_finish makes every rank
+ * walk the whole gathered dictionary twice to find the ranges of its own genes — work that does not shrink with the number of
+ * ranks.  Groups never straddle runs, so between begin and finish each rank can make the range tuples of ALL genes of its run
+ * (library.cpp:289-335 on 1/world of the records) and file them by the rank that owns the gene:
+ *
+ *   pdl_dist_preprocess_begin
+ *   -- caller: all-gather [records | genome_weights | genome_costs] --
+ *   pdl_dist_preprocess_ranges         deals the genomes (as _finish would), builds + files the tuples of this run
+ *   -- caller: all-gather [counts[world] | shared_records | groups | repeat_sample]; all-to-all the tuples (keys: 4 bytes, ranges:
+ *      8 bytes, same split sizes); the runs into one device array as before (AFTER this call: it takes the group-head bits out of
+ *      the run) --
+ *   pdl_dist_preprocess_finish_ranges  adopts the dictionary, sorts the received tuples (source-rank major) by gene
+ *
+ * `available` = 0 (gene ids beyond 22 bits, more than 256 ranks, a last run of exactly one record — the same verdict on every rank:
+ * it depends on the input and the record counts only): nothing was built, the caller goes on with pdl_dist_preprocess_finish. */
+typedef struct {
+    int available;
+    const uint32_t *d_keys;         /* device, tuples grouped by destination rank, record order inside: (owner << 24 | gene) */
+    const uint64_t *d_ranges;       /* device, {first posting in the GATHERED dictionary, postings | min(own count, 1023) << 22} */
+    const uint64_t *counts;         /* host, [world]: tuples for each rank; valid until the next call on this context */
+    uint64_t total;
+    uint64_t shared_records, groups, repeat_sample;   /* counters over this run; the caller hands their sums over the ranks to _finish_ranges */
+} pdl_dist_ranges;
 
 typedef struct { float score, perc, tr_perc; uint32_t row, column, first_group; } pdl_dist_cell;   /* cell (row, column) as its row's rank computed it */
 
@@ -278,6 +304,14 @@ PDL_API int pdl_dist_preprocess_begin(pdl_ctx *, const uint8_t *d_residues, cons
  * dictionary and computes them itself. */
 PDL_API int pdl_dist_preprocess_finish(pdl_ctx *, void *d_postings_all, uint64_t total_records, const uint64_t *genome_weights /* may be NULL */,
                                        pdl_cost *out_cost /* may be NULL */);
+/* run_records: [world] records of every rank's run; genome_weights / genome_costs: [G] element-wise sums over the ranks */
+PDL_API int pdl_dist_preprocess_ranges(pdl_ctx *, const uint64_t *run_records, const uint64_t *genome_weights, const uint64_t *genome_costs,
+                                       pdl_dist_ranges *out);
+/* d_keys / d_ranges: the received tuples, source-rank major (what all_to_all leaves); they are sorted in place / into library
+ * memory and must stay valid, like d_postings_all, until the next preprocess.  counter_sums: [3] shared_records, groups,
+ * repeat_sample summed over the ranks.  pdl_genome_cost then answers for every genome; pdl_sequence_costs is not available. */
+PDL_API int pdl_dist_preprocess_finish_ranges(pdl_ctx *, void *d_postings_all, uint64_t total_records, uint32_t *d_keys, uint64_t *d_ranges,
+                                              uint64_t n_tuples, const uint64_t *counter_sums /* [3] */, pdl_cost *out_cost /* may be NULL */);
 PDL_API int pdl_dist_genome_owner(const pdl_ctx *, uint32_t *out_owner /* [G] */);
 PDL_API int pdl_dist_score_begin(pdl_ctx *, pdl_dist_outbox *out);
 PDL_API int pdl_dist_score_finish(pdl_ctx *, const pdl_dist_cell *d_inbox, uint64_t n_inbox);

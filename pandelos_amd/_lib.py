@@ -55,7 +55,7 @@ class PdlTimings(C.Structure):
                 ("tier2_rows", C.c_uint32),
                 ("dist_begin_ms", C.c_float), ("dist_finish_ms", C.c_float), ("dist_score_begin_ms", C.c_float),
                 ("dist_score_finish_ms", C.c_float), ("walked_lookups", C.c_uint64), ("outbox_cells", C.c_uint64),
-                ("inbox_cells", C.c_uint64), ("aside_reloads", C.c_uint64), ("aside_repeats", C.c_uint32), ("tier1_rows", C.c_uint32), ("reshard_ms", C.c_float), ("reserved1", C.c_uint32)]
+                ("inbox_cells", C.c_uint64), ("aside_reloads", C.c_uint64), ("aside_repeats", C.c_uint32), ("tier1_rows", C.c_uint32), ("reshard_ms", C.c_float), ("dist_ranges_ms", C.c_float)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if not n.startswith("reserved")}
@@ -67,7 +67,12 @@ class PdlEdges(C.Structure):
 
 class PdlDistSlice(C.Structure):
     _fields_ = [("d_postings", C.c_void_p), ("records", C.c_uint64), ("kmers", C.c_uint64),
-                ("genome_weights", C.POINTER(C.c_uint64)), ("genomes", C.c_uint32)]
+                ("genome_weights", C.POINTER(C.c_uint64)), ("genomes", C.c_uint32), ("genome_costs", C.POINTER(C.c_uint64))]
+
+
+class PdlDistRanges(C.Structure):
+    _fields_ = [("available", C.c_int32), ("d_keys", C.c_void_p), ("d_ranges", C.c_void_p), ("counts", C.POINTER(C.c_uint64)),
+                ("total", C.c_uint64), ("shared_records", C.c_uint64), ("groups", C.c_uint64), ("repeat_sample", C.c_uint64)]
 
 
 class PdlDistOutbox(C.Structure):
@@ -89,6 +94,7 @@ EXPORTS = ("pdl_create", "pdl_destroy", "pdl_last_error", "pdl_preprocess", "pdl
            "pdl_genome_cost", "pdl_sequence_costs", "pdl_set_genome_shard", "pdl_score_all", "pdl_compute_scores",
            "pdl_free_scores", "pdl_scores_counts", "pdl_get_dictionary", "pdl_get_rank_table", "pdl_get_timings",
            "pdl_version", "pdl_set_option", "pdl_dist_preprocess_begin", "pdl_dist_preprocess_finish",
+           "pdl_dist_preprocess_ranges", "pdl_dist_preprocess_finish_ranges",
            "pdl_dist_genome_owner", "pdl_dist_score_begin", "pdl_dist_score_finish", "pdl_copy_device",
            "pdl_compute_edges", "pdl_free_edges", "pdl_ingest_faa", "pdl_ingest_genome_name", "pdl_preprocess_ingested",
            "pdl_scan_faa", "pdl_pin_arrived", "pdl_pin_checksum")
@@ -134,6 +140,8 @@ def load():
     lib.pdl_dist_preprocess_begin.argtypes = [vp, vp, vp, vp, u32, u64, i32, u32, u32, C.POINTER(PdlDistSlice)]
     lib.pdl_dist_preprocess_begin.restype = i32
     lib.pdl_dist_preprocess_finish.argtypes = [vp, vp, u64, vp, C.POINTER(PdlCost)]; lib.pdl_dist_preprocess_finish.restype = i32
+    lib.pdl_dist_preprocess_ranges.argtypes = [vp, vp, vp, vp, C.POINTER(PdlDistRanges)]; lib.pdl_dist_preprocess_ranges.restype = i32
+    lib.pdl_dist_preprocess_finish_ranges.argtypes = [vp, vp, u64, vp, vp, u64, vp, C.POINTER(PdlCost)]; lib.pdl_dist_preprocess_finish_ranges.restype = i32
     lib.pdl_dist_genome_owner.argtypes = [vp, vp]; lib.pdl_dist_genome_owner.restype = i32
     lib.pdl_dist_score_begin.argtypes = [vp, C.POINTER(PdlDistOutbox)]; lib.pdl_dist_score_begin.restype = i32
     lib.pdl_dist_score_finish.argtypes = [vp, vp, u64]; lib.pdl_dist_score_finish.restype = i32

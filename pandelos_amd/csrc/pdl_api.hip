@@ -270,6 +270,7 @@ int pdl_sequence_costs(const pdl_ctx *cc, uint64_t *out_cost, uint32_t *out_kseq
     std::lock_guard<std::mutex> lk(c->mu);
     if (!c->preprocessed) return PDL_ERR_STATE;
     PDL_GUARD_BEGIN
+    if (c->dist && c->dist_sender) PDL_FAIL(PDL_ERR_STATE, "per-gene costs are not kept by a multi-GPU build whose range lists came from the senders (pdl_genome_cost works)");
     PDL_HIP(hipSetDevice(c->device));
     pdl_ensure_costs(c);
     PDL_HIP(hipMemcpyAsync(out_cost, c->cost.p, (size_t) c->N * 8, hipMemcpyDeviceToHost, c->stream));
@@ -572,6 +573,7 @@ int pdl_dist_preprocess_begin(pdl_ctx *c, const uint8_t *d_residues, const uint6
     pdl_run_dist_begin(c, k);
     out->d_postings = c->post.p; out->records = c->U_slice; out->kmers = c->M_slice;
     out->genome_weights = c->h_run_weights.data(); out->genomes = c->G;
+    out->genome_costs = c->h_run_costs.data();
     return PDL_OK;
     PDL_GUARD_END(c)
 }
@@ -581,12 +583,45 @@ int pdl_dist_preprocess_finish(pdl_ctx *c, void *d_postings_all, uint64_t total_
     std::lock_guard<std::mutex> lk(c->mu);
     PDL_GUARD_BEGIN
     if (!c->dist || c->dist_stage != 1) PDL_FAIL(PDL_ERR_STATE, "pdl_dist_preprocess_finish without pdl_dist_preprocess_begin");
+    if (c->dist_sender) PDL_FAIL(PDL_ERR_STATE, "pdl_dist_preprocess_ranges built this run's range tuples (and took its group-head bits out): finish with pdl_dist_preprocess_finish_ranges");
     if (!d_postings_all || ((uintptr_t) d_postings_all & 7) != 0) PDL_FAIL(PDL_ERR_ARGUMENT, "the gathered dictionary must be an 8-byte aligned device array");
     if (total_records < c->U_slice) PDL_FAIL(PDL_ERR_ARGUMENT, "the gathered dictionary (%llu records) is smaller than this rank's run (%llu)",
                                              (unsigned long long) total_records, (unsigned long long) c->U_slice);
     PDL_HIP(hipSetDevice(c->device));
     c->post_ext = static_cast<uint2 *>(d_postings_all);
     pdl_run_dist_finish(c, total_records, genome_weights);
+    c->preprocessed = true;
+    fill_cost(c, out_cost);
+    return PDL_OK;
+    PDL_GUARD_END(c)
+}
+
+int pdl_dist_preprocess_ranges(pdl_ctx *c, const uint64_t *run_records, const uint64_t *genome_weights, const uint64_t *genome_costs, pdl_dist_ranges *out) {
+    if (!c || !out || !run_records || !genome_weights || !genome_costs) return PDL_ERR_ARGUMENT;
+    std::lock_guard<std::mutex> lk(c->mu);
+    PDL_GUARD_BEGIN
+    if (!c->dist || c->dist_stage != 1) PDL_FAIL(PDL_ERR_STATE, "pdl_dist_preprocess_ranges without pdl_dist_preprocess_begin");
+    PDL_HIP(hipSetDevice(c->device));
+    memset(out, 0, sizeof(*out));
+    out->available = pdl_run_dist_ranges(c, run_records, genome_weights, genome_costs) ? 1 : 0;
+    out->d_keys = c->dist_out_keys; out->d_ranges = reinterpret_cast<const uint64_t *>(c->dist_out_ranges);
+    out->counts = c->h_tuple_counts.data(); out->total = c->dist_out_total;
+    out->shared_records = c->dist_run_counters[0]; out->groups = c->dist_run_counters[1]; out->repeat_sample = c->dist_run_counters[2];
+    return PDL_OK;
+    PDL_GUARD_END(c)
+}
+
+int pdl_dist_preprocess_finish_ranges(pdl_ctx *c, void *d_postings_all, uint64_t total_records, uint32_t *d_keys, uint64_t *d_ranges, uint64_t n_tuples,
+                                      const uint64_t *counter_sums, pdl_cost *out_cost) {
+    if (!c || !counter_sums || ((!d_keys || !d_ranges) && n_tuples)) return PDL_ERR_ARGUMENT;
+    std::lock_guard<std::mutex> lk(c->mu);
+    PDL_GUARD_BEGIN
+    if (!c->dist || c->dist_stage != 1 || !c->dist_sender) PDL_FAIL(PDL_ERR_STATE, "pdl_dist_preprocess_finish_ranges without a pdl_dist_preprocess_ranges that said \"available\"");
+    if (!d_postings_all || ((uintptr_t) d_postings_all & 7) != 0) PDL_FAIL(PDL_ERR_ARGUMENT, "the gathered dictionary must be an 8-byte aligned device array");
+    if (n_tuples && ((((uintptr_t) d_keys) & 3) != 0 || (((uintptr_t) d_ranges) & 7) != 0)) PDL_FAIL(PDL_ERR_ARGUMENT, "the received tuples must be aligned device arrays");
+    PDL_HIP(hipSetDevice(c->device));
+    c->post_ext = static_cast<uint2 *>(d_postings_all);
+    pdl_run_dist_finish_ranges(c, total_records, d_keys, reinterpret_cast<unsigned long long *>(d_ranges), n_tuples, counter_sums);
     c->preprocessed = true;
     fill_cost(c, out_cost);
     return PDL_OK;

@@ -258,6 +258,18 @@ struct pdl_ctx {
     std::vector<uint32_t> h_owner;            // [G] rank of every genome
     std::vector<uint64_t> h_upper_cost;       // [G] lookups above the diagonal per genome (what a rank's join walks)
     std::vector<uint64_t> h_run_weights;      // [G] the same inside this rank's run of the dictionary (summed over ranks: the deal's weights)
+    std::vector<uint64_t> h_run_costs;        // [G] lookups as the reference counts them, inside this run (summed over ranks: "Genome g cost")
+    // sender-built range lists (pdl_dist_preprocess_ranges / _finish_ranges): every rank makes the range tuples of ITS run and
+    // files them by the rank that owns the gene; the owners only sort what they receive
+    bool dist_sender = false;                 // the range lists of this build came from the senders (per-gene costs are not kept then)
+    int dist_tail = -1;                       // last rank with a non-empty interval (known to every rank: the cuts depend on the input only)
+    uint64_t run_base = 0, dist_total = 0;    // first record of this run in the gathered dictionary; records of all runs
+    DevBuf seq_owner;                         // u8 [N] rank that owns the gene
+    DevBuf tuple_off;                         // u32 [world + 1] where each destination's tuples start in the outbox
+    std::vector<uint64_t> h_tuple_counts;     // [world]
+    uint32_t *dist_out_keys = nullptr;        // the outbox (inside `scratch`): (owner << 24 | gene), packed range
+    unsigned long long *dist_out_ranges = nullptr;
+    uint64_t dist_out_total = 0, dist_run_counters[3] = {0, 0, 0};     // shared records, groups, repeat statistic of this run
     DevBuf owner_of_genome;                   // u32 [G]
     DevView local_genome;                     // u32 [G] index in the shard, 0xffffffff for other ranks' genomes
     DevBuf outbox;                            // pdl_dist_cell [remote mirrored cells], grouped by destination rank
@@ -393,6 +405,8 @@ void pdl_run_preprocess(pdl_ctx *c, int kvalue, bool only_complexity);
 void pdl_run_reshard(pdl_ctx *c);       // the range lists again, for the genomes of c->shard, on the dictionary that is there
 void pdl_run_dist_begin(pdl_ctx *c, int kvalue);
 void pdl_run_dist_finish(pdl_ctx *c, uint64_t total_records, const uint64_t *genome_weights);
+bool pdl_run_dist_ranges(pdl_ctx *c, const uint64_t *run_records, const uint64_t *genome_weights, const uint64_t *genome_costs);   // false: not available for this build (use pdl_run_dist_finish)
+void pdl_run_dist_finish_ranges(pdl_ctx *c, uint64_t total_records, uint32_t *d_keys, unsigned long long *d_ranges, uint64_t n_tuples, const uint64_t *counter_sums);
 void pdl_run_score_all(pdl_ctx *c);
 void pdl_run_dist_score_begin(pdl_ctx *c);
 void pdl_run_dist_score_finish(pdl_ctx *c, const pdl_dist_cell *d_inbox, uint64_t n_inbox);
@@ -405,7 +419,7 @@ inline uint2 *pdl_postings(const pdl_ctx *c) { return c->post_ext ? c->post_ext 
 
 // event helpers
 enum { EV_HIST, EV_RANK, EV_SORT1, EV_DICT, EV_SORT2, EV_RANGES, EV_JOIN, EV_JOIN_OVF, EV_ORDER, EV_PRE_TOTAL, EV_SCORE_TOTAL,
-       EV_DIST_BEGIN, EV_DIST_FINISH, EV_DIST_SCORE_FINISH, EV_COUNT };
+       EV_DIST_BEGIN, EV_DIST_FINISH, EV_DIST_SCORE_FINISH, EV_DIST_RANGES, EV_COUNT };
 
 // An event record is a marker packet between two dispatches (a few us of idle stream each); the per-stage pairs can be
 // switched off ("stage_timers" 0) when only the totals and the join's launch time are wanted (bench.py's timed loop).

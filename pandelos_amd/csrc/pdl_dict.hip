@@ -450,6 +450,7 @@ struct GroupTileArgs {
     unsigned long long *pay8;                   // ... (non-null) the packed 8-byte range {first posting | (postings + (min(own count, 1023) << 22)) << 32},
                                                 //     carried through the gene sort as its payload: no gather afterwards
     unsigned long long *head_bits;              // WRITE: [tiles * 16] the head bits it removes from the postings, kept for the lazy cost pass
+    uint32_t pos_base;                          // WRITE, packed ranges: added to every first posting (a run of a multi-GPU build: its place in the gathered dictionary)
     unsigned long long *cost;                   // per-gene total_visited (library.cpp:327): last members (WRITE), all shared records (COUNT, RECORD_COSTS)
     unsigned long long *counters;               // COUNT: [0] += records in groups >= 2, [1] += such groups, [3] += records whose k-mer repeats inside its gene (range modes);  WRITE: [2] += lookups of the
                                                 //        records that belong to this context (library.cpp:327 summed: "Total cost")
@@ -621,7 +622,7 @@ __global__ __launch_bounds__(GW_THREADS) void k_group_waves(GroupTileArgs a) {
                     const uint32_t at = tile_prefix + cnt_tile + (uint32_t) __popcll(rb & lt_mask);
                     const uint32_t start = MODE == 0 ? gs : u + 1;
                     a.key2[at] = po[j].x;
-                    if (a.pay8) a.pay8[at] = (unsigned long long) start | ((unsigned long long) ((ge - start) | (min(cnt, 1023u) << 22)) << 32);
+                    if (a.pay8) a.pay8[at] = (unsigned long long) (start + a.pos_base) | ((unsigned long long) ((ge - start) | (min(cnt, 1023u) << 22)) << 32);
                     else a.tuples[at] = make_uint4(start, ge - start, cnt, ge - gs);     // {first posting, postings, own count, group size}
                 } else if (MODE == 1 || MODE == 2) {
                     if (!a.pay8 && ge - gs >= 2 && u + 1 == ge && mine)                  // (packed ranges: per-gene costs are made on demand)
@@ -1006,6 +1007,20 @@ __global__ __launch_bounds__(256) void k_genes_of_rank(const uint32_t *__restric
     const uint32_t s = blockIdx.x * 256 + threadIdx.x;
     if (s < n_seq) in_shard[s] = owner[genome_of[s]] == rank ? 1 : 0;
 }
+// seq_owner[gene] = rank that owns the gene's genome
+__global__ __launch_bounds__(256) void k_gene_owner(const uint32_t *__restrict__ genome_of, const uint32_t *__restrict__ owner, uint32_t n_seq,
+                                                    uint8_t *__restrict__ seq_owner) {
+    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+    if (s < n_seq) seq_owner[s] = (uint8_t) owner[genome_of[s]];
+}
+// key = owner(gene) << 24 | gene: one radix pass on the top byte files the tuples by destination, in record order
+__global__ __launch_bounds__(256) void k_owner_keys(uint32_t *__restrict__ key, const uint64_t *d_n, const uint8_t *__restrict__ seq_owner) {
+    const uint32_t n = (uint32_t) *d_n;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint32_t g = key[i];
+        key[i] = g | ((uint32_t) seq_owner[g] << 24);
+    }
+}
 
 // Also adds up total_visited (library.cpp:327) = the group sizes over a gene's ranges: the list is gene-sorted, so a
 // wave holds one or two genes as a rule; one atomic per (wave, gene).
@@ -1038,15 +1053,16 @@ __global__ __launch_bounds__(256) void k_gather_ranges(const uint32_t *__restric
     }
 }
 // seq_off[s] = first range of gene s in the gene-sorted list (lower bound), seq_off[N] = number of ranges
+// (the sorted field of a key is (key >> shift) & mask: the tuples of a multi-GPU build carry the owner rank above the gene)
 __global__ __launch_bounds__(256) void k_seq_offsets(const uint32_t *__restrict__ key_sorted, const uint64_t *d_n, uint32_t n_seq,
-                                                     uint32_t *__restrict__ seq_off) {
+                                                     uint32_t *__restrict__ seq_off, uint32_t shift = 0, uint32_t mask = 0xffffffffu) {
     const uint32_t n = (uint32_t) *d_n;
     const uint32_t s = blockIdx.x * 256 + threadIdx.x;
     if (s > n_seq) return;
     uint32_t lo = 0, hi = n;
     while (lo < hi) {
         uint32_t mid = lo + ((hi - lo) >> 1);
-        if (key_sorted[mid] < s) lo = mid + 1; else hi = mid;
+        if (((key_sorted[mid] >> shift) & mask) < s) lo = mid + 1; else hi = mid;
     }
     seq_off[s] = lo;
 }
@@ -1483,7 +1499,7 @@ static void dictionary_pipeline(pdl_ctx *c, bool only_complexity) {
 void pdl_run_preprocess(pdl_ctx *c, int kvalue, bool only_complexity) {
     hipStream_t st = c->stream;
     ev_begin(c, EV_PRE_TOTAL);
-    c->dist = false; c->dist_stage = 0; c->post_ext = nullptr;
+    c->dist = false; c->dist_stage = 0; c->post_ext = nullptr; c->dist_sender = false;
     stage_alphabet_and_lengths(c, kvalue, only_complexity);
     if (c->key64) dictionary_pipeline<uint64_t>(c, only_complexity);
     else dictionary_pipeline<uint32_t>(c, only_complexity);
@@ -1536,6 +1552,8 @@ static void dist_slice_pipeline(pdl_ctx *c) {
     const uint32_t b_lo = cut(me), b_hi = cut(me + 1);
     const uint64_t m_own = pre[b_hi] - pre[b_lo];
     c->M_slice = m_own;
+    c->dist_tail = -1;                      // the last rank whose interval holds k-mers: it holds the dictionary's last record
+    for (uint32_t w = 0; w < W; w++) if (pre[cut(w + 1)] > pre[cut(w)]) c->dist_tail = (int) w;
     // 3. this rank's k-mers, in stream order (the sort below is stable: equal ranks keep ascending gene order)
     KeyT *sel_k = c->keys_b.as<KeyT>();
     uint32_t *sel_v = c->vals_b.as<uint32_t>();
@@ -1547,8 +1565,15 @@ static void dist_slice_pipeline(pdl_ctx *c) {
         KeyT *keys_in = sel_k, *keys_out = c->keys_a.as<KeyT>();
         uint32_t *vals_in = sel_v, *vals_out = c->vals_a.as<uint32_t>();
         stage_sort_and_dedup<KeyT>(c, keys_in, keys_out, vals_in, vals_out, m_own);
-        // every genome's lookups above the diagonal inside this run (groups never straddle runs): summed over the ranks
-        // they are the weights of the genome deal (the fold of the globally last record is not in them: they only balance)
+        // The reference folds the dictionary's LAST record into the group before it (library.cpp:300-306).  That record is in
+        // the run of the last rank with k-mers, and so is the group it joins whenever that run has two records or more (groups
+        // never straddle runs): the fold is made here, on the run, and travels with it (it is idempotent: the finish that
+        // looks at the gathered dictionary finds nothing left to do; a last run of ONE record is left to that finish).
+        if ((int) me == c->dist_tail)
+            hipLaunchKernelGGL(k_fold_last_record, dim3(1), dim3(1024), 0, st, c->post.as<uint2>(), c->recpos.as<uint32_t>(), d_scal + 0);
+        // every genome's lookups inside this run (groups never straddle runs), as the reference counts them and above the
+        // diagonal: summed over the ranks the former are "Genome g cost" (exact when the fold above was made), the latter the
+        // weights of the genome deal
         GroupTileArgs ga{};
         ga.post = c->post.as<uint2>(); ga.n_bound = m_own; ga.d_n = d_scal + 0;
         const uint32_t grid = group_tiles_plan(c, ga);
@@ -1572,13 +1597,17 @@ void pdl_run_dist_begin(pdl_ctx *c, int kvalue) {
     if (c->key64) dist_slice_pipeline<uint64_t>(c); else dist_slice_pipeline<uint32_t>(c);
     ev_end(c, EV_DIST_BEGIN);
     c->h_run_weights.assign(c->G, 0);
+    c->h_run_costs.assign(c->G, 0);
+    c->dist_sender = false;
     if (c->M_slice) {
         PinRead rd(c);
         const uint64_t *pu = rd.add<uint64_t>(c->scalars.as<uint64_t>(), 1);
         const uint64_t *pw = rd.add<uint64_t>(c->scalars.as<uint64_t>() + PDL_CTL_GCOST + c->G, c->G);
+        const uint64_t *pf = rd.add<uint64_t>(c->scalars.as<uint64_t>() + PDL_CTL_GCOST, c->G);
         rd.sync();
         c->U_slice = pu[0];
         c->h_run_weights.assign(pw, pw + c->G);
+        c->h_run_costs.assign(pf, pf + c->G);
     } else {
         PDL_HIP(hipStreamSynchronize(st));
     }
@@ -1666,5 +1695,167 @@ void pdl_run_dist_finish(pdl_ctx *c, uint64_t total, const uint64_t *weights) {
     c->tm.ranges_ms = ev_ms(c, EV_RANGES);
     c->tm.dist_finish_ms = ev_ms(c, EV_DIST_FINISH);
     c->tm.preprocess_total_ms = c->tm.dist_begin_ms + c->tm.dist_finish_ms;
+    c->dist_stage = 2;
+}
+
+// ---- sender-built range lists ----------------------------------------------------------------------------------------------------
+// pdl_run_dist_finish makes every rank walk the WHOLE gathered dictionary twice (COUNT, WRITE) to find the ranges of its own
+// genes: work that does not shrink with the number of ranks.  Groups never straddle runs, so everything a range tuple says —
+// the gene, where its postings start, how many there are, the gene's own count — is known to the rank that holds the run, up to
+// the run's place in the gathered array, which the record counts give.  Here a rank makes the tuples of ALL genes in its run
+// (1/world of the records, no "is this gene mine" per record), files them by the rank that owns the gene (one stable radix
+// pass on the owner byte: record order survives, so a gene's ranges still arrive in (rank, gene) order when the sources are
+// concatenated in rank order), and the owners sort what they receive by gene.
+static void dist_deal_genomes(pdl_ctx *c, const uint64_t *weights) {
+    hipStream_t st = c->stream;
+    c->h_upper_cost.assign(weights, weights + c->G);
+    lpt_owner(c->h_upper_cost, c->world, c->h_owner);
+    c->shard.clear();
+    for (uint32_t g = 0; g < c->G; g++) if (c->h_owner[g] == c->rank) c->shard.push_back(g);
+    c->shard_set = true;
+    c->dict_shard = c->shard;
+    c->tasks_ready = false;
+    c->owner_of_genome.alloc((size_t) c->G * 4);
+    PDL_HIP(hipMemcpyAsync(c->owner_of_genome.p, c->h_owner.data(), (size_t) c->G * 4, hipMemcpyHostToDevice, st));
+}
+
+bool pdl_run_dist_ranges(pdl_ctx *c, const uint64_t *run_records, const uint64_t *weights, const uint64_t *costs) {
+    hipStream_t st = c->stream;
+    uint64_t *d_scal = c->scalars.as<uint64_t>();
+    const uint32_t W = c->world, me = c->rank;
+    uint64_t total = 0, base = 0;
+    int tail = -1;
+    for (uint32_t r = 0; r < W; r++) { if (r < me) base += run_records[r]; total += run_records[r]; if (run_records[r]) tail = (int) r; }
+    if (run_records[me] != c->U_slice) PDL_FAIL(PDL_ERR_ARGUMENT, "run_records[%u] = %llu, this rank's run holds %llu records", me, (unsigned long long) run_records[me], (unsigned long long) c->U_slice);
+    if (total == 0) PDL_FAIL(PDL_ERR_EMPTY, "empty dictionary");
+    if (total >= 0xfffff000ull) PDL_FAIL(PDL_ERR_UNSUPPORTED, "a dictionary of %llu records needs 64-bit record indices", (unsigned long long) total);
+    c->dist_total = total; c->run_base = base;
+    c->h_tuple_counts.assign(W, 0);
+    c->dist_out_keys = nullptr; c->dist_out_ranges = nullptr; c->dist_out_total = 0;
+    c->dist_run_counters[0] = c->dist_run_counters[1] = c->dist_run_counters[2] = 0;
+    // Not this way (every rank decides the same: all of it is a function of the input and of the record counts): packed ranges
+    // need gene ids of 22 bits, the owner a byte; a last run of ONE record has not been folded (the group it joins is in
+    // another rank's run).
+    c->dist_sender = c->N < (1u << 22) && W <= 256 && tail == c->dist_tail && (run_records[tail] >= 2 || total == 1);
+    if (!c->dist_sender) return false;
+    ev_begin(c, EV_DIST_RANGES);
+    dist_deal_genomes(c, weights);
+    c->h_genome_cost.assign(costs, costs + c->G);       // exact: the fold was made before the runs were counted
+    c->seq_owner.alloc(c->N);
+    hipLaunchKernelGGL(k_gene_owner, dim3((c->N + 255) / 256), dim3(256), 0, st, c->d_gen, c->owner_of_genome.as<uint32_t>(), c->N, c->seq_owner.as<uint8_t>());
+    const uint64_t n_run = c->U_slice;
+    if (n_run) {
+        PDL_HIP(hipMemsetAsync(d_scal + 2, 0, sizeof(uint64_t), st));
+        PDL_HIP(hipMemsetAsync(d_scal + 10, 0, 4 * sizeof(uint64_t), st));
+        GroupTileArgs ga{};
+        ga.post = c->post.as<uint2>(); ga.n_bound = n_run; ga.d_n = d_scal + 0;       // (the run's record count is still where K-rle left it)
+        const uint32_t grid = group_tiles_plan(c, ga);
+        ga.cost = c->cost.as<unsigned long long>();
+        ga.counters = reinterpret_cast<unsigned long long *>(d_scal + 10);
+        ga.genome_of = c->d_gen; ga.n_genomes = c->G;
+        hipLaunchKernelGGL(k_range_count<1>, dim3(grid), dim3(GW_THREADS), 0, st, ga);
+        hipLaunchKernelGGL(k_tile_prefix, dim3((ga.n_blocks + 3) / 4), dim3(256), 0, st, ga.tile_sums, ga.d_n, ga.n_bound, ga.chunk_sums, ga.n_blocks);
+        hipLaunchKernelGGL(k_scan_tile_scan, dim3(1), dim3(1024), 0, st, ga.chunk_sums, ga.n_blocks, d_scal + 2, (uint64_t *) nullptr);
+        PDL_HIP(hipGetLastError());
+        uint64_t n_t = 0;
+        {
+            PinRead rd(c);
+            const uint64_t *pn = rd.add<uint64_t>(d_scal + 2, 1);
+            rd.sync();
+            n_t = pn[0];
+        }
+        const uint64_t cap = std::max<uint64_t>(n_t, 1);
+        c->scratch.alloc(cap * (2 * sizeof(uint64_t) + 2 * sizeof(uint32_t)) + 64);
+        unsigned long long *pay_a = c->scratch.as<unsigned long long>(), *pay_b = pay_a + cap;
+        uint32_t *k2a = reinterpret_cast<uint32_t *>(pay_b + cap), *k2b = k2a + cap;
+        c->head_bits.alloc(((n_run + GW_TILE - 1) / GW_TILE) * GW_ROUNDS * sizeof(uint64_t));
+        ga.head_bits = c->head_bits.as<unsigned long long>();
+        ga.key2 = k2a; ga.tuples = nullptr; ga.pay8 = pay_a; ga.pos_base = (uint32_t) base;
+        launch_group_tiles<1, 1, false, false>(c, ga, grid);
+        if (n_t) {
+            hipLaunchKernelGGL(k_owner_keys, dim3((uint32_t) std::min<uint64_t>((n_t + 255) / 256, (uint64_t) c->cus * 16)), dim3(256), 0, st, k2a, d_scal + 2, c->seq_owner.as<uint8_t>());
+            pdl_sort_pairs<uint32_t, unsigned long long>(c, k2a, k2b, pay_a, pay_b, n_t, 32, false, nullptr, 24);      // -> (k2b, pay_b), by destination
+            c->tuple_off.alloc(((size_t) W + 1) * sizeof(uint32_t));
+            hipLaunchKernelGGL(k_seq_offsets, dim3((W + 1 + 255) / 256), dim3(256), 0, st, k2b, d_scal + 2, W, c->tuple_off.as<uint32_t>(), 24u, 0xffu);
+            PDL_HIP(hipGetLastError());
+            c->dist_out_keys = k2b; c->dist_out_ranges = pay_b; c->dist_out_total = n_t;
+        }
+        PinRead rd(c);
+        const uint64_t *pc = rd.add<uint64_t>(d_scal + 10, 4);
+        const uint32_t *po = n_t ? rd.add<uint32_t>(c->tuple_off.as<uint32_t>(), W + 1) : nullptr;
+        rd.sync();
+        c->dist_run_counters[0] = pc[0]; c->dist_run_counters[1] = pc[1]; c->dist_run_counters[2] = pc[3];
+        if (po) {
+            for (uint32_t r = 0; r < W; r++) c->h_tuple_counts[r] = po[r + 1] - po[r];
+            if (po[W] != n_t) PDL_FAIL(PDL_ERR_DEVICE, "range tuples: %llu made, %u filed", (unsigned long long) n_t, po[W]);
+        }
+    }
+    ev_end(c, EV_DIST_RANGES);
+    PDL_HIP(hipStreamSynchronize(st));
+    c->tm.dist_ranges_ms = ev_ms(c, EV_DIST_RANGES);
+    return true;
+}
+
+// the owner's side: the gathered dictionary is adopted, the received tuples (source-rank major) are sorted by gene
+void pdl_run_dist_finish_ranges(pdl_ctx *c, uint64_t total, uint32_t *d_keys, unsigned long long *d_ranges, uint64_t n_in, const uint64_t *sums) {
+    hipStream_t st = c->stream;
+    uint64_t *d_scal = c->scalars.as<uint64_t>();
+    ev_begin(c, EV_DIST_FINISH);
+    if (total != c->dist_total) PDL_FAIL(PDL_ERR_ARGUMENT, "the gathered dictionary holds %llu records, the runs add up to %llu", (unsigned long long) total, (unsigned long long) c->dist_total);
+    if (n_in >= 0xfffff000ull) PDL_FAIL(PDL_ERR_UNSUPPORTED, "more than 2^32 range tuples for one rank");
+    uint64_t *h_u = reinterpret_cast<uint64_t *>(c->pin);       // (pinned scratch; rewritten only by the next PinRead, which comes after a sync)
+    if (!h_u) PDL_FAIL(PDL_ERR_DEVICE, "pinned scratch missing");
+    h_u[0] = total; h_u[1] = 0; h_u[2] = n_in;
+    PDL_HIP(hipMemcpyAsync(d_scal + 0, h_u, 3 * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    PDL_HIP(hipMemsetAsync(d_scal + 4, 0, sizeof(uint64_t), st));          // (k_genome_cost adds the k-mer statistics up: sum, max, ~min)
+    PDL_HIP(hipMemsetAsync(d_scal + 7, 0, 2 * sizeof(uint64_t), st));
+    PDL_HIP(hipMemsetAsync(d_scal + 9, 0, 7 * sizeof(uint64_t), st));
+    PDL_HIP(hipMemsetAsync(d_scal + PDL_CTL_GCOST, 0, 2 * (size_t) c->G * sizeof(uint64_t), st));
+    PDL_HIP(hipMemsetAsync(c->cost.p, 0, (size_t) c->N * sizeof(uint64_t), st));
+    ev_begin(c, EV_SORT2);
+    const uint32_t seq_bits = std::max<uint32_t>(1, bit_length64(c->N ? c->N - 1 : 0));
+    c->seq_off.alloc(((size_t) c->N + 1) * sizeof(uint32_t));
+    const uint64_t cap = std::max<uint64_t>(n_in, 1);
+    // (the outbox in `scratch` has been delivered: its memory takes the sort's second pair)
+    c->scratch.alloc(cap * (sizeof(uint64_t) + sizeof(uint32_t)) + 64);
+    unsigned long long *pay_a = d_ranges, *pay_b = c->scratch.as<unsigned long long>();
+    uint32_t *k2a = d_keys, *k2b = reinterpret_cast<uint32_t *>(pay_b + cap);
+    c->dist_out_keys = nullptr; c->dist_out_ranges = nullptr; c->dist_out_total = 0;
+    if (n_in) pdl_sort_pairs<uint32_t, unsigned long long>(c, k2a, k2b, pay_a, pay_b, n_in, seq_bits, false, nullptr);      // the gene bits only: the owner byte is the same everywhere
+    else { k2b = k2a; pay_b = pay_a; }
+    ev_end(c, EV_SORT2);
+    ev_begin(c, EV_RANGES);
+    c->ranges8 = reinterpret_cast<const uint2 *>(n_in ? pay_b : c->scratch.as<unsigned long long>());
+    hipLaunchKernelGGL(k_seq_offsets, dim3((c->N + 1 + 255) / 256), dim3(256), 0, st, n_in ? k2b : reinterpret_cast<uint32_t *>(c->scratch.p), d_scal + 2, c->N,
+                       c->seq_off.as<uint32_t>(), 0u, 0xffffffu);
+    PDL_HIP(hipGetLastError());
+    ev_end(c, EV_RANGES);
+    c->upper_only = true;
+    // the k-mer statistics of the genes (the per-gene costs are all zero here: what it adds up per genome is not used)
+    hipLaunchKernelGGL(k_genome_cost, dim3(std::min<uint32_t>((c->N + 255) / 256, 128)), dim3(256), 0, st, c->cost.as<unsigned long long>(),
+                       c->kseq_len.as<uint32_t>(), c->d_gen, c->N, reinterpret_cast<unsigned long long *>(d_scal + PDL_CTL_GCOST),
+                       reinterpret_cast<unsigned long long *>(d_scal + 4), reinterpret_cast<unsigned long long *>(d_scal + 7),
+                       reinterpret_cast<unsigned long long *>(d_scal + 8));
+    PDL_HIP(hipGetLastError());
+    if (!c->tasks_ready) pdl_prepare_tasks(c);           // host work + small uploads while the device sorts
+    {
+        PinRead rd(c);
+        const uint64_t *pt = rd.add<uint64_t>(d_scal, 9);
+        const uint32_t *lbe = lookback_error_word(c, rd);
+        rd.sync();
+        lookback_check(c, lbe);
+        c->sum_kseq = pt[4]; c->max_kseq = pt[7]; c->min_kseq = pt[8] == 0 ? 1 : ~pt[8];
+    }
+    c->U = total; c->Ushared = sums[0]; c->NG = sums[1]; c->Urepeat = sums[2];
+    c->P = 0;
+    for (uint32_t g : c->shard) c->P += c->h_genome_cost[g];
+    c->costs_ready = true;                   // per genome, from the runs' counts; per gene: not kept by this build (pdl_sequence_costs says so)
+    ev_end(c, EV_DIST_FINISH);
+    ev_end(c, EV_PRE_TOTAL);
+    PDL_HIP(hipStreamSynchronize(st));
+    c->tm.sort_seq_ms = ev_ms(c, EV_SORT2);
+    c->tm.ranges_ms = ev_ms(c, EV_RANGES);
+    c->tm.dist_finish_ms = ev_ms(c, EV_DIST_FINISH);
+    c->tm.preprocess_total_ms = c->tm.dist_begin_ms + c->tm.dist_ranges_ms + c->tm.dist_finish_ms;
     c->dist_stage = 2;
 }

@@ -9,9 +9,14 @@ its own HBM and scores a disjoint set of genomes; what the shared memory did is 
                ``library.cpp:270-287``.  The runs are all-gathered *in place* into one device array —
                W−1 sends and W−1 receives per rank, posted together, so each of the 7 xGMI links of a
                GPU carries one peer's run (no ring, no merge: the concatenation in rank order is the
-               dictionary).  ``pdl_dist_preprocess_finish`` builds groups, deals the genomes
-               (longest-processing-time on exact lookup counts, identical on every rank) and this
-               rank's posting-range lists.
+               dictionary).  The genomes are dealt by longest-processing-time on exact lookup counts
+               (identical on every rank).  The posting-range lists are made by the SENDERS: every rank
+               builds the range tuples of all genes of its own run (groups never straddle runs) and
+               files them by the rank that owns the gene (``pdl_dist_preprocess_ranges``); one
+               all-to-all of 12-byte tuples later the owners only sort what they received
+               (``pdl_dist_preprocess_finish_ranges``) — nobody walks the whole dictionary.  Where that
+               is not available (see the header) ``pdl_dist_preprocess_finish`` builds the lists of a
+               rank's genes from the gathered dictionary, as before.
   cells        rows only meet the genes above them (half the lookups, as on one GPU); a cell whose
                column is another rank's row travels there: one variable-size all-to-all of 24-byte
                cells (``pdl_dist_score_begin`` / ``pdl_dist_score_finish``).
@@ -156,9 +161,11 @@ class DistributedPangenes:
         self.on_device = device_collectives
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
-        self.exchange_s = {"dictionary": 0.0, "cells": 0.0}
+        self.exchange_s = {"dictionary": 0.0, "ranges": 0.0, "cells": 0.0}
+        self.sender_ranges = None          # after preprocess: the range lists came from the senders
         import os
         self.p2p_gather = os.environ.get("PDL_DIST_GATHER", "p2p") != "broadcast"     # how the runs are gathered on device tensors
+        self.use_sender = os.environ.get("PDL_DIST_RANGES", "sender") != "owner"      # "owner": every rank builds its range lists from the gathered dictionary
 
     def _sync(self):
         """The collectives run on torch's current stream of the device; the library works on its own: wait on the host."""
@@ -195,6 +202,21 @@ class DistributedPangenes:
                     dist.broadcast(host[offs[p]:offs[p + 1]], src=p)
             full.copy_(host)
 
+    def _all_to_all_rows(self, recv, send, recv_counts, send_counts):
+        """Variable-size all-to-all of the rows of two device tensors (host-staged without device collectives)."""
+        import torch
+        import torch.distributed as dist
+        n_in, n_out = int(np.sum(recv_counts)), int(np.sum(send_counts))
+        rs, ss = [int(x) for x in recv_counts], [int(x) for x in send_counts]
+        if self.on_device:
+            dist.all_to_all_single(recv[:n_in], send[:n_out], output_split_sizes=rs, input_split_sizes=ss)
+        else:
+            h_recv = torch.empty((n_in,) + tuple(recv.shape[1:]), dtype=recv.dtype)
+            dist.all_to_all_single(h_recv, send[:n_out].cpu(), output_split_sizes=rs, input_split_sizes=ss)
+            recv[:n_in].copy_(h_recv)
+            if getattr(self.dev, "type", "cpu") == "cuda":
+                torch.cuda.synchronize(self.dev)
+
     def preprocess(self, k, t_res, t_off, t_gen, n_genes, n_residues):
         import time
         import torch
@@ -203,17 +225,54 @@ class DistributedPangenes:
         ptr, records, _ = nat.dist_preprocess_begin(k, t_res.data_ptr(), t_off.data_ptr(), t_gen.data_ptr(), n_genes, n_residues,
                                                     W, r, keepalive=(t_res, t_off, t_gen))
         t0 = time.perf_counter()
-        # one small all-gather: [records of my run | every genome's lookups inside it]; their sum deals the genomes
-        mine = torch.from_numpy(np.concatenate([[records], nat.run_weights]).astype(np.int64))
+        # one small all-gather: [records of my run | every genome's lookups inside it: above the diagonal, and as the reference counts
+        # them]; summed over the ranks the former deal the genomes, the latter are "Genome g cost"
+        G = len(nat.run_weights)
+        mine = torch.from_numpy(np.concatenate([[records], nat.run_weights, nat.run_costs]).astype(np.int64))
+        cdev = self.dev if self.on_device else None
         if self.on_device:
             mine = mine.to(self.dev)
         allv = torch.empty(W * mine.numel(), dtype=torch.int64, device=mine.device)       # (flat: gloo takes no 2-D output)
-        with ExchangeDeadline("dictionary: record counts and genome weights (all-gather)", r, W, f"{mine.numel() * 8} bytes per rank"):
+        with ExchangeDeadline("dictionary: record counts, genome weights and costs (all-gather)", r, W, f"{mine.numel() * 8} bytes per rank"):
             dist.all_gather_into_tensor(allv, mine)
             allv = allv.cpu().numpy().reshape(W, -1)
-        offs = exclusive_offsets(allv[:, 0])
-        weights = allv[:, 1:].sum(axis=0)
+        run_records = allv[:, 0]
+        offs = exclusive_offsets(run_records)
+        weights, costs = allv[:, 1:1 + G].sum(axis=0), allv[:, 1 + G:1 + 2 * G].sum(axis=0)
         total = int(offs[-1])
+        self.exchange_s["dictionary"] = time.perf_counter() - t0
+        # the range tuples of my run, filed by owner (takes the group-head bits out of the run: the runs travel afterwards)
+        made = nat.dist_preprocess_ranges(run_records, weights, costs) if self.use_sender else None
+        self.sender_ranges = made is not None
+        t0 = time.perf_counter()
+        recv_k = recv_r = None
+        if made is not None:
+            kptr, rptr, send_counts, ctr = made
+            mine2 = torch.from_numpy(np.concatenate([send_counts, ctr]).astype(np.int64))
+            if self.on_device:
+                mine2 = mine2.to(self.dev)
+            allc = torch.empty(W * mine2.numel(), dtype=torch.int64, device=mine2.device)
+            with ExchangeDeadline("ranges: tuple counts and run counters (all-gather)", r, W, f"{mine2.numel() * 8} bytes per rank"):
+                dist.all_gather_into_tensor(allc, mine2)
+                allc = allc.cpu().numpy().reshape(W, -1)
+            recv_counts, sums = allc[:, r].copy(), allc[:, W:].sum(axis=0)
+            n_out, n_in = int(send_counts.sum()), int(recv_counts.sum())
+            send_k = torch.empty(max(n_out, 1), dtype=torch.int32, device=self.dev)
+            send_r = torch.empty(max(n_out, 1), dtype=torch.int64, device=self.dev)
+            recv_k = torch.empty(max(n_in, 1), dtype=torch.int32, device=self.dev)
+            recv_r = torch.empty(max(n_in, 1), dtype=torch.int64, device=self.dev)
+            if n_out:
+                nat.copy_device(send_k.data_ptr(), kptr, n_out * 4)
+                nat.copy_device(send_r.data_ptr(), rptr, n_out * 8)
+            detail = ("sending " + ", ".join(f"{int(c) * 12} to rank {d}" for d, c in enumerate(send_counts) if d != r) +
+                      " bytes; receiving " + ", ".join(f"{int(c) * 12} from rank {p}" for p, c in enumerate(recv_counts) if p != r) + " bytes")
+            with ExchangeDeadline("ranges: 12-byte tuples (two all-to-alls: keys, packed ranges)", r, W, detail):
+                self._all_to_all_rows(recv_k, send_k, recv_counts, send_counts)
+                self._all_to_all_rows(recv_r, send_r, recv_counts, send_counts)
+                self._sync()
+            del send_k, send_r
+            self.exchange_s["ranges"] = time.perf_counter() - t0
+            t0 = time.perf_counter()
         full = torch.empty(max(total, 1), dtype=torch.int64, device=self.dev)      # 8-byte records {gene, count|flag}
         if records:
             nat.copy_device(full.data_ptr() + int(offs[r]) * 8, ptr, records * 8)
@@ -221,8 +280,12 @@ class DistributedPangenes:
                               "sending %d bytes to each peer; receiving %s bytes" % (records * 8, ", ".join(f"{int(offs[p + 1] - offs[p]) * 8} from rank {p}" for p in range(W) if p != r))):
             self._all_gather_runs(full, offs)
             self._sync()
-        self.exchange_s["dictionary"] = time.perf_counter() - t0
-        nat.dist_preprocess_finish(full.data_ptr(), total, genome_weights=weights, keepalive=full)
+        self.exchange_s["dictionary"] += time.perf_counter() - t0
+        if made is not None:
+            nat.dist_preprocess_finish_ranges(full.data_ptr(), total, recv_k.data_ptr(), recv_r.data_ptr(), n_in, sums,
+                                              keepalive=(full, recv_k, recv_r))
+        else:
+            nat.dist_preprocess_finish(full.data_ptr(), total, genome_weights=weights, keepalive=full)
         return nat.cost
 
     def score_all(self):
@@ -246,17 +309,8 @@ class DistributedPangenes:
         detail = ("sending " + ", ".join(f"{int(c) * _lib.DIST_CELL_BYTES} to rank {d}" for d, c in enumerate(send_counts) if d != self.rank) +
                   " bytes; receiving " + ", ".join(f"{int(c) * _lib.DIST_CELL_BYTES} from rank {p}" for p, c in enumerate(recv_counts) if p != self.rank) + " bytes")
         with ExchangeDeadline("cells: 24-byte cells (all-to-all)", self.rank, W, detail):
-            if self.on_device:
-                dist.all_to_all_single(recv[:n_in], send[:n_out], output_split_sizes=[int(x) for x in recv_counts],
-                                       input_split_sizes=[int(x) for x in send_counts])
-                self._sync()
-            else:
-                h_recv = torch.empty((n_in, 6), dtype=torch.int32)
-                dist.all_to_all_single(h_recv, send[:n_out].cpu(), output_split_sizes=[int(x) for x in recv_counts],
-                                       input_split_sizes=[int(x) for x in send_counts])
-                recv[:n_in].copy_(h_recv)
-                if self.dev.type == "cuda":
-                    torch.cuda.synchronize(self.dev)
+            self._all_to_all_rows(recv, send, recv_counts, send_counts)
+            self._sync()
         self.exchange_s["cells"] = time.perf_counter() - t0
         nat.dist_score_finish(recv.data_ptr(), n_in, keepalive=recv)
 
@@ -276,10 +330,11 @@ class LocalRanks:
     Same library calls in the same order as ``DistributedPangenes``; per-rank device times come from the
     contexts' own HIP-event timings (``tools/shard_step_time.py``)."""
 
-    def __init__(self, world: int, device: int = -1, stream=None, flags: int = 0, exchange_weights: bool = True):
+    def __init__(self, world: int, device: int = -1, stream=None, flags: int = 0, exchange_weights: bool = True, sender_ranges: bool = True):
         from .pangene_native import PangeneNative
         self.world = world
         self.exchange_weights = exchange_weights      # False: every rank computes the deal's weights itself (one more pass)
+        self.sender_ranges = sender_ranges and exchange_weights     # the range lists come from the senders where the library can (else: owners)
         self.ranks = [PangeneNative.open(device=device, stream=stream, flags=flags) for _ in range(world)]
 
     def close(self):
@@ -295,6 +350,14 @@ class LocalRanks:
         total = int(offs[-1])
         self.run_records = [rec for _, rec, _ in runs]
         weights = np.sum([n.run_weights for n in self.ranks], axis=0) if self.exchange_weights else None
+        made = None
+        if self.sender_ranges:               # every rank: the tuples of its run, by owner (before the runs are "gathered": it takes their head bits out)
+            costs = np.sum([n.run_costs for n in self.ranks], axis=0)
+            made = [n.dist_preprocess_ranges(self.run_records, weights, costs) for n in self.ranks]
+            assert all(m is None for m in made) or all(m is not None for m in made), "ranks disagree on who builds the range lists"
+            if made[0] is None:
+                made = None
+        self.used_sender_ranges = made is not None
         self.dictionaries = []
         for r, n in enumerate(self.ranks):
             full = torch.empty(max(total, 1), dtype=torch.int64, device=t_res.device)
@@ -302,8 +365,29 @@ class LocalRanks:
                 if rec:
                     n.copy_device(full.data_ptr() + int(offs[p]) * 8, ptr, rec * 8)
             self.dictionaries.append(full)
-        for n, full in zip(self.ranks, self.dictionaries):
-            n.dist_preprocess_finish(full.data_ptr(), total, genome_weights=weights, keepalive=full)
+        if made is None:
+            for n, full in zip(self.ranks, self.dictionaries):
+                n.dist_preprocess_finish(full.data_ptr(), total, genome_weights=weights, keepalive=full)
+        else:
+            cmat = np.stack([m[2] for m in made])            # [src][dst] tuples
+            sums = np.sum([m[3] for m in made], axis=0)
+            self.tuple_counts = cmat
+            inboxes = []
+            for d, n in enumerate(self.ranks):       # "all-to-all": column d of the count matrix, source-rank major (every inbox is
+                n_in = int(cmat[:, d].sum())         # filled before any rank finishes: a finish reuses the memory of its rank's outbox)
+                recv_k = torch.empty(max(n_in, 1), dtype=torch.int32, device=t_res.device)
+                recv_r = torch.empty(max(n_in, 1), dtype=torch.int64, device=t_res.device)
+                at = 0
+                for s_ in range(W):
+                    cnt = int(cmat[s_, d])
+                    if cnt:
+                        o = int(cmat[s_, :d].sum())
+                        n.copy_device(recv_k.data_ptr() + at * 4, made[s_][0] + o * 4, cnt * 4)
+                        n.copy_device(recv_r.data_ptr() + at * 8, made[s_][1] + o * 8, cnt * 8)
+                        at += cnt
+                inboxes.append((recv_k, recv_r, n_in))
+            for n, full, (recv_k, recv_r, n_in) in zip(self.ranks, self.dictionaries, inboxes):
+                n.dist_preprocess_finish_ranges(full.data_ptr(), total, recv_k.data_ptr(), recv_r.data_ptr(), n_in, sums, keepalive=(full, recv_k, recv_r))
         self.owner = self.ranks[0].dist_genome_owner()
         for n in self.ranks[1:]:
             assert np.array_equal(n.dist_genome_owner(), self.owner), "ranks disagree on the genome deal"
@@ -342,16 +426,19 @@ class RanksInTurn:
     device side by side (BASELINE configs[4]: every rank ranks all 0.9 G k-mers).  Same library calls as
     ``DistributedPangenes``; what the exchanges would carry is kept in device tensors between the passes:
 
-      pass 1   every rank: dist_preprocess_begin                          -> its run is kept (the "all-gather")
-      pass 2   every rank: begin, finish, score_begin                     -> its outbox is kept (the "all-to-all")
-      pass 3   every rank: begin, finish, score_begin, score_finish       -> ``visit(rank, nat, genomes)`` sees its results
+      pass 1   every rank: begin                                                   -> record counts, genome weights and costs
+      pass 2   every rank: begin, ranges                                           -> its run and its tuples are kept
+      pass 3   every rank: begin, ranges, finish, score_begin                      -> its outbox is kept (the "all-to-all")
+      pass 4   every rank: begin, ranges, finish, score_begin, score_finish        -> ``visit(rank, nat, genomes)`` sees its results
 
-    (``tools/shard_step_time.py`` is the timing version of the same walk.)"""
+    (``sender_ranges=False``, or a build the library cannot make that way: no "ranges", the owners build their lists in
+    "finish".  ``tools/shard_step_time.py`` is the timing version of the same walk.)"""
 
-    def __init__(self, world: int, nat=None):
+    def __init__(self, world: int, nat=None, sender_ranges: bool = True):
         from .pangene_native import PangeneNative
         self.world = world
         self.nat = nat or PangeneNative.open()
+        self.sender_ranges = sender_ranges
 
     def run(self, k, t_res, t_off, t_gen, n_genes, n_residues, visit):
         import torch
@@ -360,25 +447,65 @@ class RanksInTurn:
         def begin(r):
             return nat.dist_preprocess_begin(k, t_res.data_ptr(), t_off.data_ptr(), t_gen.data_ptr(), n_genes, n_residues, W, r)
 
-        saved, weights = [], None
+        weights = costs = None
+        records = []
+        for r in range(W):
+            _, rec, _ = begin(r)
+            records.append(rec)
+            weights = nat.run_weights.copy() if weights is None else weights + nat.run_weights
+            costs = nat.run_costs.copy() if costs is None else costs + nat.run_costs
+        self.run_records = records
+        total = int(sum(records))
+        sender = self.sender_ranges
+        saved, keys, rngs, tcounts, ctrs = [], [], [], [], []
         for r in range(W):
             ptr, rec, _ = begin(r)
-            weights = nat.run_weights.copy() if weights is None else weights + nat.run_weights
+            if sender:
+                made = nat.dist_preprocess_ranges(records, weights, costs)
+                if made is None:
+                    assert r == 0, "ranks disagree on who builds the range lists"
+                    sender = False
+                else:
+                    n_t = int(made[2].sum())
+                    kt = torch.empty(max(n_t, 1), dtype=torch.int32, device=dev)
+                    rt = torch.empty(max(n_t, 1), dtype=torch.int64, device=dev)
+                    if n_t:
+                        nat.copy_device(kt.data_ptr(), made[0], n_t * 4)
+                        nat.copy_device(rt.data_ptr(), made[1], n_t * 8)
+                    keys.append(kt[:n_t]); rngs.append(rt[:n_t]); tcounts.append(made[2]); ctrs.append(made[3])
             run_t = torch.empty(max(rec, 1), dtype=torch.int64, device=dev)
             if rec:
                 nat.copy_device(run_t.data_ptr(), ptr, rec * 8)
             saved.append(run_t[:rec])
-        self.run_records = [int(t.numel()) for t in saved]
-        total = int(sum(self.run_records))
+        self.used_sender_ranges = sender
         full0 = torch.cat(saved) if total else torch.zeros(1, dtype=torch.int64, device=dev)
         del saved
-        full = torch.empty_like(full0)          # finish works in place (head bits, the fold of the last record): a fresh copy per rank
+        full = full0 if sender else torch.empty_like(full0)     # the owners' finish works in place (head bits, the fold of the last record): a fresh copy per rank
+        if sender:
+            tmat, sums = np.stack(tcounts), np.sum(ctrs, axis=0)
+            self.tuple_counts = tmat
 
         def upto_score_begin(r):
             begin(r)
-            full.copy_(full0)
-            torch.cuda.synchronize(dev)
-            nat.dist_preprocess_finish(full.data_ptr(), total, genome_weights=weights)
+            if sender:
+                nat.dist_preprocess_ranges(records, weights, costs)
+                n_in = int(tmat[:, r].sum())
+                rk = torch.empty(max(n_in, 1), dtype=torch.int32, device=dev)
+                rr = torch.empty(max(n_in, 1), dtype=torch.int64, device=dev)
+                at = 0
+                for s_ in range(W):               # source-rank major, as the all-to-all delivers
+                    c = int(tmat[s_, r])
+                    if c:
+                        o = int(tmat[s_, :r].sum())
+                        rk[at:at + c] = keys[s_][o:o + c]
+                        rr[at:at + c] = rngs[s_][o:o + c]
+                        at += c
+                torch.cuda.synchronize(dev)
+                nat.dist_preprocess_finish_ranges(full.data_ptr(), total, rk.data_ptr(), rr.data_ptr(), n_in, sums, keepalive=(full, rk, rr))
+            else:
+                full.copy_(full0)
+                torch.cuda.synchronize(dev)
+                nat.dist_preprocess_finish(full.data_ptr(), total, genome_weights=weights)
             return nat.dist_score_begin(W)
 
         outbox, counts = [], []
@@ -400,11 +527,11 @@ class RanksInTurn:
             n_in = int(cmat[:, r].sum())
             inbox = torch.empty((max(n_in, 1), 6), dtype=torch.int32, device=dev)
             at = 0
-            for s in range(W):
-                c = int(cmat[s, r])
+            for s_ in range(W):
+                c = int(cmat[s_, r])
                 if c:
-                    o = int(cmat[s, :r].sum())
-                    inbox[at:at + c] = outbox[s][o:o + c]
+                    o = int(cmat[s_, :r].sum())
+                    inbox[at:at + c] = outbox[s_][o:o + c]
                     at += c
             upto_score_begin(r)
             nat.dist_score_finish(inbox.data_ptr(), n_in, keepalive=inbox)

@@ -180,8 +180,36 @@ class PangeneNative:
         sl = _lib.PdlDistSlice()
         self._check(self._lib.pdl_dist_preprocess_begin(self._ctx, d_residues, d_offsets, d_genome_of, n_sequences, n_residues,
                                                         int(k), int(world), int(rank), C.byref(sl)))
-        self.run_weights = np.array([sl.genome_weights[g] for g in range(sl.genomes)], dtype=np.int64)
+        self.run_weights = np.ctypeslib.as_array(sl.genome_weights, shape=(sl.genomes,)).astype(np.int64) if sl.genomes else np.zeros(0, np.int64)
+        self.run_costs = np.ctypeslib.as_array(sl.genome_costs, shape=(sl.genomes,)).astype(np.int64) if sl.genomes else np.zeros(0, np.int64)
         return sl.d_postings or 0, int(sl.records), int(sl.kmers)
+
+    def dist_preprocess_ranges(self, run_records, genome_weights, genome_costs):
+        """The range tuples of this rank's run, filed by the rank that owns the gene (between begin and finish; the runs are
+        gathered AFTER it).  ``run_records`` [world]; ``genome_weights`` / ``genome_costs`` [G]: the ranks' ``run_weights`` /
+        ``run_costs`` summed.  -> None when this build cannot go that way (every rank gets the same answer: use
+        ``dist_preprocess_finish``), else (device pointer of the keys, of the packed ranges, tuples per destination rank [world],
+        counters [3] of this run: shared records, groups, repeat statistic)."""
+        rr = np.ascontiguousarray(run_records, dtype=np.uint64)
+        w = np.ascontiguousarray(genome_weights, dtype=np.uint64)
+        cs = np.ascontiguousarray(genome_costs, dtype=np.uint64)
+        out = _lib.PdlDistRanges()
+        self._check(self._lib.pdl_dist_preprocess_ranges(self._ctx, rr.ctypes.data, w.ctypes.data, cs.ctypes.data, C.byref(out)))
+        if not out.available:
+            return None
+        counts = np.array([out.counts[d] for d in range(len(rr))], dtype=np.int64)
+        assert int(counts.sum()) == out.total
+        return out.d_keys or 0, out.d_ranges or 0, counts, np.array([out.shared_records, out.groups, out.repeat_sample], dtype=np.int64)
+
+    def dist_preprocess_finish_ranges(self, d_postings_all: int, total_records: int, d_keys: int, d_ranges: int, n_tuples: int,
+                                      counter_sums, keepalive=None) -> None:
+        """Adopts the gathered dictionary and sorts the received tuples (source-rank major) by gene.  ``counter_sums`` [3]: the
+        ranks' counters summed.  The three device arrays must stay alive until the next preprocess (``keepalive``)."""
+        self._keep_dict = keepalive
+        self.cost = _lib.PdlCost()
+        sums = np.ascontiguousarray(counter_sums, dtype=np.uint64)
+        self._check(self._lib.pdl_dist_preprocess_finish_ranges(self._ctx, d_postings_all, int(total_records), d_keys, d_ranges, int(n_tuples),
+                                                                sums.ctypes.data, C.byref(self.cost)))
 
     def dist_preprocess_finish(self, d_postings_all: int, total_records: int, genome_weights=None, keepalive=None) -> None:
         """``genome_weights``: the ranks' ``run_weights`` summed (identical on every rank); None lets the library compute them."""

@@ -79,7 +79,13 @@ class _FakeRank:
         self.records = 3 + 4 * rank                                   # uneven runs; rank 0 has the shortest
         self.run = torch.arange(self.records, dtype=torch.int64) + (rank << 32)
         self.run_weights = np.arange(genomes, dtype=np.int64) * (rank + 1)
+        self.run_costs = np.arange(genomes, dtype=np.int64) * (rank + 3) + 1
         self.cost = "cost"
+        # range tuples for rank d: (rank + 2) * (d + 1) of them (also for myself: a rank owns genes of its own run too)
+        self.tcounts = np.array([(rank + 2) * (d + 1) for d in range(world)], dtype=np.int64)
+        self.tkeys = torch.tensor([(d << 24) | (rank << 8) | i for d in range(world) for i in range(int(self.tcounts[d]))], dtype=torch.int32)
+        self.tranges = torch.tensor([(rank << 40) | (d << 20) | i for d in range(world) for i in range(int(self.tcounts[d]))], dtype=torch.int64)
+        self.tctr = np.array([10 + rank, 20 + rank, 30 + rank], dtype=np.int64)
         # cells for rank d: (rank + 1) * (d + 2) of them, none for myself
         self.counts = np.array([0 if d == rank else (rank + 1) * (d + 2) for d in range(world)], dtype=np.int64)
         cells = []
@@ -100,6 +106,22 @@ class _FakeRank:
         self.seen["dictionary"] = keepalive.clone()
         self.seen["total"] = total
         self.seen["weights"] = np.asarray(genome_weights).copy()
+        self.seen["flow"] = "owner"
+
+    def dist_preprocess_ranges(self, run_records, genome_weights, genome_costs):
+        self.seen["run_records"] = [int(x) for x in run_records]
+        self.seen["weights"] = np.asarray(genome_weights).copy()
+        self.seen["costs"] = np.asarray(genome_costs).copy()
+        self.run += (1 << 48)                    # (in place: the call takes the head bits out of the run: the runs must travel AFTER it)
+        return self.tkeys.data_ptr(), self.tranges.data_ptr(), self.tcounts, self.tctr
+
+    def dist_preprocess_finish_ranges(self, ptr, total, d_keys, d_ranges, n_tuples, counter_sums, keepalive=None):
+        full, rk, rr = keepalive
+        self.seen["dictionary"] = full.clone()
+        self.seen["total"] = total
+        self.seen["tuples"] = (rk[:n_tuples].tolist(), rr[:n_tuples].tolist())
+        self.seen["sums"] = [int(x) for x in counter_sums]
+        self.seen["flow"] = "sender"
 
     def dist_score_begin(self, world):
         return self.outbox.data_ptr(), self.counts
@@ -117,6 +139,11 @@ def _exchange_worker(rank, world, port, out, flow="host"):
         os.environ["PDL_DIST_GATHER"] = "broadcast"
     else:
         os.environ.pop("PDL_DIST_GATHER", None)
+    if flow.endswith("-owner"):               # the owners build their range lists from the gathered dictionary (no tuple exchange)
+        os.environ["PDL_DIST_RANGES"] = "owner"
+        flow = flow[:-6]
+    else:
+        os.environ.pop("PDL_DIST_RANGES", None)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         fake = _FakeRank(rank, world)
@@ -126,13 +153,14 @@ def _exchange_worker(rank, world, port, out, flow="host"):
         t = torch.zeros(1)
         dp.preprocess(3, t, t, t, 1, 1)
         dp.score_all()
-        out.put((rank, fake.seen["dictionary"].tolist(), fake.seen["total"], fake.seen["weights"].tolist(), fake.seen["inbox"].tolist()))
+        out.put((rank, fake.seen["dictionary"].tolist(), fake.seen["total"], fake.seen["weights"].tolist(), fake.seen["inbox"].tolist(),
+                 {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in fake.seen.items() if k in ("flow", "tuples", "sums", "costs", "run_records")}))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world,flow", [(2, "host"), (3, "host"), (2, "p2p"), (3, "p2p"), (4, "p2p"), (3, "broadcast")])
+@pytest.mark.parametrize("world,flow", [(2, "host"), (3, "host"), (2, "p2p"), (3, "p2p"), (4, "p2p"), (3, "broadcast"), (3, "host-owner"), (3, "p2p-owner")])
 def test_driver_exchanges_runs_and_cells_in_rank_order(world, flow):
     import queue
     import torch.multiprocessing as mp
@@ -155,11 +183,20 @@ def test_driver_exchanges_runs_and_cells_in_rank_order(world, flow):
         p.join(60)
         assert p.exitcode == 0
     fakes = [_FakeRank(r, world) for r in range(world)]
-    dictionary = [int(x) for f in fakes for x in f.run.tolist()]                  # the runs in rank order = the dictionary
+    sender = not flow.endswith("-owner")
+    dictionary = [int(x) + ((1 << 48) if sender else 0) for f in fakes for x in f.run.tolist()]      # the runs in rank order = the dictionary (as "ranges" left them)
     weights = np.sum([f.run_weights for f in fakes], axis=0).tolist()
     for r in range(world):
-        d, total, w, inbox = got[r]
+        d, total, w, inbox, more = got[r]
         assert d[:total] == dictionary and total == len(dictionary) and w == weights
+        assert more["flow"] == ("sender" if sender else "owner")
+        if sender:        # the tuples every rank filed for r, source-rank major, keys and ranges alike; the counters and costs summed
+            want_k = [(r << 24) | (s << 8) | i for s in range(world) for i in range(int(fakes[s].tcounts[r]))]
+            want_r = [(s << 40) | (r << 20) | i for s in range(world) for i in range(int(fakes[s].tcounts[r]))]
+            assert [list(x) for x in more["tuples"]] == [want_k, want_r]
+            assert more["sums"] == np.sum([f.tctr for f in fakes], axis=0).tolist()
+            assert more["costs"] == np.sum([f.run_costs for f in fakes], axis=0).tolist()
+            assert more["run_records"] == [f.records for f in fakes]
         want = [[s, r, i, 7, 8, 9] for s in range(world) for i in range(int(fakes[s].counts[r]))]     # source-major, as all-to-all delivers
         assert inbox == want
 

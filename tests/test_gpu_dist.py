@@ -26,21 +26,26 @@ def _device_inputs(res, off, gen):
     return t_res, t_off, t_gen
 
 
-def _local(world, res, off, gen, k, flags=0, exchange_weights=True):
+def _local(world, res, off, gen, k, flags=0, exchange_weights=True, sender_ranges=True):
     from pandelos_amd.distributed import LocalRanks
     t = _device_inputs(res, off, gen)
-    lr = LocalRanks(world, flags=flags, exchange_weights=exchange_weights)
+    lr = LocalRanks(world, flags=flags, exchange_weights=exchange_weights, sender_ranges=sender_ranges)
     cost = lr.preprocess(k, *t, len(gen), len(res))
     return lr, cost
 
 
+@pytest.mark.parametrize("ranges", ["sender", "owner"])      # who builds the range lists: the rank that holds the run (tuples travel), or the rank that owns the gene
 @pytest.mark.parametrize("world", [1, 2, 3, 5])
 @pytest.mark.parametrize("name", ["synth_5x60x80_k3", "synth_5x60x80_k13", "synth_5x60x80_k16_hash", "low_complexity", "q1_fold",
                                   "q1_fold_onto_singleton", "q1_fold_same_gene_twice", "readme4_k1", "readme4_k2",
                                   "short_and_duplicate_genes", "interleaved_genomes"])
-def test_ranks_together_reproduce_the_fixture(name, world):
+def test_ranks_together_reproduce_the_fixture(name, world, ranges):
     res, off, gen, k, fx = H.load_small(name)
-    lr, cost = _local(world, res, off, gen, k)
+    lr, cost = _local(world, res, off, gen, k, sender_ranges=ranges == "sender")
+    # (the senders' flow is the library's call: a last run of exactly one record — tiny sets over many ranks — leaves the lists to the owners)
+    assert not lr.used_sender_ranges or ranges == "sender"
+    if ranges == "sender" and name in ("synth_5x60x80_k3", "synth_5x60x80_k13", "low_complexity"):
+        assert lr.used_sender_ranges
     assert lr.total_cost == int(fx["total_cost"]) and (cost.sequences, cost.genomes) == (int(fx["sequences"]), int(fx["genomes"]))
     assert sum(lr.run_records) == cost.dictionary_records
     assert [lr.genome_cost(g) for g in range(cost.genomes)] == [int(x) for x in fx["genome_cost"]]     # each from its owner (library.cpp:535-538)
@@ -65,6 +70,7 @@ def test_ranks_together_reproduce_the_fixture(name, world):
 def test_ranks_together_reproduce_the_reference_digest(world, weights, name):
     res, off, gen, k, d = H.load_large(name)
     lr, cost = _local(world, res, off, gen, k, exchange_weights=weights)
+    assert lr.used_sender_ranges == weights              # (without exchanged weights the owners build their lists, as in round 2)
     assert lr.total_cost == d["total_cost"]
     lr.score_all()
     H.assert_scores_match_digest(lambda g: lr.generate_scores_part(g).as_dict(), d, f"W={world}")

@@ -6,9 +6,10 @@ This tool plays every rank of a W-rank job in turn on a single context (so even 
 buffers at a time), with device copies in place of the collectives, and reports for every rank the device time of
 each call (HIP events inside the library) and the bytes it would send and receive:
 
-  pass 1   every rank: pdl_dist_preprocess_begin                 -> its run is kept (the "all-gather")
-  pass 2   every rank: begin, finish (on its own copy of the gathered dictionary), score_begin -> its outbox is kept
-  pass 3   every rank: begin, finish, score_begin, score_finish (inbox = what the others listed for it)
+  pass 1   every rank: pdl_dist_preprocess_begin                 -> record counts, genome weights and costs
+  pass 2   every rank: begin, ranges                              -> its run and its range tuples are kept (the "all-gather", the "all-to-all")
+  pass 3   every rank: begin, ranges, finish, score_begin        -> its outbox is kept
+  pass 4   every rank: begin, ranges, finish, score_begin, score_finish (inbox = what the others listed for it)
            [--check: every genome's Scores block against tests/golden/digests_baseline.json]
 
 Projection printed with the measurements: step(W) = slowest rank's device time + the two exchanges at --link-gbps per
@@ -39,6 +40,7 @@ def main():
     ap.add_argument("--repeat", type=int, default=2, help="timed repetitions of every call (the fastest counts)")
     ap.add_argument("--link-gbps", type=float, default=100.0, help="effective one-way rate of one xGMI link for the projection (peak ~153)")
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--ranges", choices=["sender", "owner"], default="sender", help="who builds the range lists (owner: every rank from the gathered dictionary, the flow of round 2)")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
 
@@ -84,8 +86,8 @@ def main():
             report["worlds"]["1"] = {"ranks": [best], "slowest_device_ms": best["device_ms"], "projected_step_ms": best["device_ms"], "speedup": 1.0}
             print(f"W=1: {best['device_ms']:.3f} ms (preprocess {best['preprocess_ms']:.3f}, score {best['score_ms']:.3f})", flush=True)
             continue
-        # ---- pass 1: the runs ------------------------------------------------------------------------------------------
-        runs, begin_ms, saved = [], [], []
+        # ---- pass 1: record counts, genome weights and costs --------------------------------------------------------------
+        runs, begin_ms = [], []
         for r in range(W):
             t = []
             for _ in range(args.repeat):
@@ -94,25 +96,77 @@ def main():
             runs.append((rec, kmers))
             begin_ms.append(min(t))
             weights = nat.run_weights.copy() if r == 0 else weights + nat.run_weights
+            costs = nat.run_costs.copy() if r == 0 else costs + nat.run_costs
+        records = [rec for rec, _ in runs]
+        offs = exclusive_offsets(records)
+        total = int(offs[-1])
+        # ---- pass 2: the range tuples of every run (sender flow), the runs kept -------------------------------------------
+        sender = args.ranges == "sender"
+        saved, keys, rngs, tcounts, ctrs, ranges_ms = [], [], [], [], [], []
+        for r in range(W):
+            t = [0.0]
+            ptr, rec, _ = begin(W, r)
+            if sender:
+                made = nat.dist_preprocess_ranges(records, weights, costs)
+                t = [nat.timings()["dist_ranges_ms"]]
+                for _ in range(args.repeat - 1):
+                    ptr, rec, _ = begin(W, r)
+                    made = nat.dist_preprocess_ranges(records, weights, costs)
+                    t.append(nat.timings()["dist_ranges_ms"])
+                if made is None:
+                    sender = False
+                else:
+                    n_t = int(made[2].sum())
+                    kt = torch.empty(max(n_t, 1), dtype=torch.int32, device=dev)
+                    rt = torch.empty(max(n_t, 1), dtype=torch.int64, device=dev)
+                    if n_t:
+                        nat.copy_device(kt.data_ptr(), made[0], n_t * 4)
+                        nat.copy_device(rt.data_ptr(), made[1], n_t * 8)
+                    keys.append(kt[:n_t]); rngs.append(rt[:n_t]); tcounts.append(made[2]); ctrs.append(made[3])
+            ranges_ms.append(min(t))
             run_t = torch.empty(max(rec, 1), dtype=torch.int64, device=dev)      # (the next begin overwrites the context's run)
             if rec:
                 nat.copy_device(run_t.data_ptr(), ptr, rec * 8)
             saved.append(run_t[:rec])
-        offs = exclusive_offsets([rec for rec, _ in runs])
-        total = int(offs[-1])
         full0 = torch.cat(saved) if total else torch.zeros(1, dtype=torch.int64, device=dev)
         del saved
-        full = torch.empty_like(full0)
-        # ---- pass 2: finish + score_begin, outboxes kept --------------------------------------------------------------
+        full = full0 if sender else torch.empty_like(full0)
+        if sender:
+            tmat, sums = np.stack(tcounts), np.sum(ctrs, axis=0)
+
+        def tuples_for(r):
+            n_in = int(tmat[:, r].sum())
+            rk = torch.empty(max(n_in, 1), dtype=torch.int32, device=dev)
+            rr = torch.empty(max(n_in, 1), dtype=torch.int64, device=dev)
+            at = 0
+            for s_ in range(W):
+                c = int(tmat[s_, r])
+                if c:
+                    o = int(tmat[s_, :r].sum())
+                    rk[at:at + c] = keys[s_][o:o + c]
+                    rr[at:at + c] = rngs[s_][o:o + c]
+                    at += c
+            return rk, rr, n_in
+
+        def upto_finish(r):
+            begin(W, r)
+            if sender:
+                nat.dist_preprocess_ranges(records, weights, costs)
+                rk, rr, n_in = tuples_for(r)               # (the sort works in these buffers: a fresh copy per repetition)
+                torch.cuda.synchronize()
+                nat.dist_preprocess_finish_ranges(full.data_ptr(), total, rk.data_ptr(), rr.data_ptr(), n_in, sums, keepalive=(full, rk, rr))
+            else:
+                full.copy_(full0)
+                torch.cuda.synchronize()
+                nat.dist_preprocess_finish(full.data_ptr(), total, genome_weights=weights)
+
+        # ---- pass 3: finish + score_begin, outboxes kept --------------------------------------------------------------
         finish_ms, sbegin_ms, outbox, out_counts, ranks_info = [], [], [], [], []
         owner = None
         for r in range(W):
             tf, ts = [], []
             for _ in range(args.repeat):
-                begin(W, r)
-                full.copy_(full0)
-                torch.cuda.synchronize()
-                nat.dist_preprocess_finish(full.data_ptr(), total, genome_weights=weights)
+                upto_finish(r)
                 tf.append(nat.timings()["dist_finish_ms"])
                 ptr, counts = nat.dist_score_begin(W)
                 ts.append(nat.timings()["dist_score_begin_ms"])
@@ -129,8 +183,10 @@ def main():
                                "rows": int(tm["scored_rows"]), "walked_lookups": int(tm["walked_lookups"]), "join_ms": tm["join_ms"],
                                "sort_rank_ms": tm["sort_rank_ms"], "rank_ms": tm["rank_ms"], "sort_seq_ms": tm["sort_seq_ms"], "ranges_ms": tm["ranges_ms"],
                                "outbox_cells": n_out, "aside_repeats": int(tm["aside_repeats"]), "aside_reloads": int(tm["aside_reloads"]), "tier1_rows": int(tm["tier1_rows"])})
+            if sender:
+                ranks_info[-1].update({"tuples_made": int(tmat[r].sum()), "tuples_received": int(tmat[:, r].sum())})
         cmat = np.stack(out_counts)                  # [src][dst]
-        # ---- pass 3: score_finish (+ check) -------------------------------------------------------------------------------
+        # ---- pass 4: score_finish (+ check) -------------------------------------------------------------------------------
         sfinish_ms = []
         ok = True
         for r in range(W):
@@ -145,10 +201,7 @@ def main():
                     at += c
             t = []
             for _ in range(args.repeat):
-                begin(W, r)
-                full.copy_(full0)
-                torch.cuda.synchronize()
-                nat.dist_preprocess_finish(full.data_ptr(), total, genome_weights=weights)
+                upto_finish(r)
                 nat.dist_score_begin(W)
                 nat.dist_score_finish(inbox.data_ptr(), n_in)
                 t.append(nat.timings()["dist_score_finish_ms"])
@@ -167,28 +220,36 @@ def main():
         link = args.link_gbps * 1e9
         for r in range(W):
             info = ranks_info[r]
-            info.update({"begin_ms": begin_ms[r], "finish_ms": finish_ms[r], "score_begin_ms": sbegin_ms[r], "score_finish_ms": sfinish_ms[r]})
-            info["device_ms"] = begin_ms[r] + finish_ms[r] + sbegin_ms[r] + sfinish_ms[r]
+            info.update({"begin_ms": begin_ms[r], "ranges_ms_call": ranges_ms[r], "finish_ms": finish_ms[r], "score_begin_ms": sbegin_ms[r], "score_finish_ms": sfinish_ms[r]})
+            info["device_ms"] = begin_ms[r] + ranges_ms[r] + finish_ms[r] + sbegin_ms[r] + sfinish_ms[r]
             # what arrives at rank r: every other run over that peer's link; every peer's cells over that peer's link
             info["dictionary_recv_bytes"] = int((total - runs[r][0]) * 8)
             info["cells_recv_bytes"] = int(ranks_info[r]["inbox_cells"] * _lib.DIST_CELL_BYTES)
         biggest_run = max(rec for rec, _ in runs) * 8
         biggest_cells = int(cmat.max()) * _lib.DIST_CELL_BYTES
-        xd, xc = biggest_run / link * 1e3, biggest_cells / link * 1e3
+        biggest_tuples = int(max(tmat[s_, d] for s_ in range(W) for d in range(W) if s_ != d)) * 12 if sender and W > 1 else 0
+        xd, xc, xt = biggest_run / link * 1e3, biggest_cells / link * 1e3, biggest_tuples / link * 1e3
+        # sender flow: the owners' finish does not read the dictionary, so the gather of the runs proceeds beside it — what is left
+        # of the gather once the slowest finish is over counts
+        xd_exposed = max(0.0, xd - max(finish_ms)) if sender else xd
         slow = max(i["device_ms"] for i in ranks_info)
         w1 = report["worlds"].get("1", {}).get("slowest_device_ms")
-        entry = {"ranks": ranks_info, "slowest_device_ms": slow, "exchange_dictionary_ms_model": xd, "exchange_cells_ms_model": xc,
-                 "dictionary_bytes_total": total * 8, "cells_exchanged_total": int(cmat.sum()),
-                 "projected_step_ms": slow + xd + xc, "speedup": (w1 / (slow + xd + xc)) if w1 else None,
-                 "speedup_device_only": (w1 / slow) if w1 else None}
+        proj = slow + xt + xd_exposed + xc
+        entry = {"ranks": ranks_info, "range_lists_by": "senders" if sender else "owners", "slowest_device_ms": slow,
+                 "exchange_dictionary_ms_model": xd, "exchange_dictionary_ms_model_beside_finish": xd_exposed,
+                 "exchange_ranges_ms_model": xt, "exchange_cells_ms_model": xc,
+                 "dictionary_bytes_total": total * 8, "range_tuple_bytes_total": int(tmat.sum()) * 12 if sender else 0, "cells_exchanged_total": int(cmat.sum()),
+                 "projected_step_ms": proj, "speedup": (w1 / proj) if w1 else None,
+                 "speedup_device_only": (w1 / slow) if w1 else None,
+                 "note": "per-rank device times measured on ONE GPU; exchanges are a model (largest single message per link at the assumed rate): a projection, unmeasured on N GPUs"}
         if digests is not None:
             entry["matches_reference_digests"] = ok
         report["worlds"][str(W)] = entry
-        print(f"W={W}: slowest rank {slow:.3f} ms device (begin {max(begin_ms):.3f}, finish {max(finish_ms):.3f}, score_begin {max(sbegin_ms):.3f}, "
-              f"score_finish {max(sfinish_ms):.3f}); exchanges ~{xd:.3f} + {xc:.3f} ms at {args.link_gbps:.0f} GB/s/link; "
+        print(f"W={W} ({entry['range_lists_by']}): slowest rank {slow:.3f} ms device (begin {max(begin_ms):.3f}, ranges {max(ranges_ms):.3f}, finish {max(finish_ms):.3f}, "
+              f"score_begin {max(sbegin_ms):.3f}, score_finish {max(sfinish_ms):.3f}); exchanges ~{xt:.3f} (tuples) + {xd_exposed:.3f} of {xd:.3f} (runs) + {xc:.3f} (cells) ms at {args.link_gbps:.0f} GB/s/link; "
               f"projected speed-up {entry['speedup'] if entry['speedup'] else float('nan'):.2f}"
               + (f"; digests {'OK' if ok else 'MISMATCH'}" if digests is not None else ""), flush=True)
-        del full, full0, outbox
+        del full, full0, outbox, keys, rngs
         torch.cuda.empty_cache()
     nat.close()
     text = json.dumps(report, indent=1)

@@ -108,6 +108,28 @@ def gather_genome_owner(shard: Sequence[int], genomes: int, device=None) -> np.n
     return mine.cpu().numpy()
 
 
+# ---- library-owned device memory as a tensor (no copy) -----------------------------------------------------------------
+class _DeviceArray:
+    """What ``torch.as_tensor`` needs to alias device memory it did not allocate (the CUDA array interface, version 2)."""
+
+    def __init__(self, ptr: int, shape, typestr: str):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def device_view(ptr: int, shape, dtype, device):
+    """A tensor over ``ptr`` (an outbox of the library: valid until the next call on that context), or None where the
+    interface is not available — the caller then copies."""
+    import torch
+    typestr = {torch.int32: "<i4", torch.int64: "<i8"}[dtype]
+    if not ptr or int(np.prod(shape)) == 0 or getattr(device, "type", "cpu") != "cuda":
+        return None
+    try:
+        t = torch.as_tensor(_DeviceArray(ptr, shape, typestr), device=device)
+        return t if t.data_ptr() == ptr and t.dtype == dtype else None
+    except Exception:
+        return None
+
+
 # ---- a deadline for every exchange --------------------------------------------------------------------------------
 class ExchangeDeadline:
     """``with ExchangeDeadline(...)`` around a blocking exchange: a rank whose exchange has not completed in ``seconds`` says
@@ -257,13 +279,16 @@ class DistributedPangenes:
                 allc = allc.cpu().numpy().reshape(W, -1)
             recv_counts, sums = allc[:, r].copy(), allc[:, W:].sum(axis=0)
             n_out, n_in = int(send_counts.sum()), int(recv_counts.sum())
-            send_k = torch.empty(max(n_out, 1), dtype=torch.int32, device=self.dev)
-            send_r = torch.empty(max(n_out, 1), dtype=torch.int64, device=self.dev)
             recv_k = torch.empty(max(n_in, 1), dtype=torch.int32, device=self.dev)
             recv_r = torch.empty(max(n_in, 1), dtype=torch.int64, device=self.dev)
-            if n_out:
-                nat.copy_device(send_k.data_ptr(), kptr, n_out * 4)
-                nat.copy_device(send_r.data_ptr(), rptr, n_out * 8)
+            # the outbox is sent from where the library left it (a copy only where the tensor library cannot alias foreign memory)
+            send_k, send_r = device_view(kptr, (n_out,), torch.int32, self.dev), device_view(rptr, (n_out,), torch.int64, self.dev)
+            if send_k is None or send_r is None:
+                send_k = torch.empty(max(n_out, 1), dtype=torch.int32, device=self.dev)
+                send_r = torch.empty(max(n_out, 1), dtype=torch.int64, device=self.dev)
+                if n_out:
+                    nat.copy_device(send_k.data_ptr(), kptr, n_out * 4)
+                    nat.copy_device(send_r.data_ptr(), rptr, n_out * 8)
             detail = ("sending " + ", ".join(f"{int(c) * 12} to rank {d}" for d, c in enumerate(send_counts) if d != r) +
                       " bytes; receiving " + ", ".join(f"{int(c) * 12} from rank {p}" for p, c in enumerate(recv_counts) if p != r) + " bytes")
             with ExchangeDeadline("ranges: 12-byte tuples (two all-to-alls: keys, packed ranges)", r, W, detail):
@@ -302,10 +327,12 @@ class DistributedPangenes:
             dist.all_to_all_single(rc, sc)
             recv_counts = rc.cpu().numpy()
         n_out, n_in = int(send_counts.sum()), int(recv_counts.sum())
-        send = torch.empty((max(n_out, 1), 6), dtype=torch.int32, device=self.dev)     # pdl_dist_cell = 6 x 4 bytes
         recv = torch.empty((max(n_in, 1), 6), dtype=torch.int32, device=self.dev)
-        if n_out:
-            nat.copy_device(send.data_ptr(), ptr, n_out * _lib.DIST_CELL_BYTES)
+        send = device_view(ptr, (n_out, 6), torch.int32, self.dev)                      # pdl_dist_cell = 6 x 4 bytes, sent from the library's outbox
+        if send is None:
+            send = torch.empty((max(n_out, 1), 6), dtype=torch.int32, device=self.dev)
+            if n_out:
+                nat.copy_device(send.data_ptr(), ptr, n_out * _lib.DIST_CELL_BYTES)
         detail = ("sending " + ", ".join(f"{int(c) * _lib.DIST_CELL_BYTES} to rank {d}" for d, c in enumerate(send_counts) if d != self.rank) +
                   " bytes; receiving " + ", ".join(f"{int(c) * _lib.DIST_CELL_BYTES} from rank {p}" for p, c in enumerate(recv_counts) if p != self.rank) + " bytes")
         with ExchangeDeadline("cells: 24-byte cells (all-to-all)", self.rank, W, detail):

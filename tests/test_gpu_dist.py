@@ -189,3 +189,20 @@ def test_processes_over_torch_distributed_reproduce_the_digest(backend, world):
     assert sorted(seen) == list(range(d["genomes"]))
     for g, (z, sha) in seen.items():
         assert z == d["scoresCount"][g] and sha == d["sha256"][g], f"genome {g}"
+
+
+def test_library_memory_is_sent_in_place():
+    """The driver hands the library's outboxes to the collectives as tensors that ALIAS the memory (no copy): the tensor
+    library must accept foreign device memory through the CUDA array interface on this platform, else the driver copies."""
+    import torch
+    from pandelos_amd.distributed import device_view
+    dev = torch.device("cuda", 0)
+    base = torch.arange(24, dtype=torch.int32, device=dev)
+    v = device_view(base.data_ptr(), (4, 6), torch.int32, dev)
+    assert v is not None, "torch.as_tensor does not alias device memory here: every outbox is copied before it is sent"
+    base[7] = 1234
+    torch.cuda.synchronize()
+    assert v.data_ptr() == base.data_ptr() and int(v[1, 1]) == 1234 and v.shape == (4, 6)
+    w = device_view(base.data_ptr() + 8, (2,), torch.int64, dev)
+    assert w is not None and int(w[0]) == (3 << 32 | 2)
+    assert device_view(0, (4,), torch.int32, dev) is None and device_view(base.data_ptr(), (0,), torch.int32, dev) is None

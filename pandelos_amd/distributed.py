@@ -196,10 +196,12 @@ class DistributedPangenes:
             torch.cuda.current_stream(self.dev).synchronize()
 
     # exchange of the dictionary runs: full[offs[p] : offs[p+1]] <- rank p's run, for every p
-    def _all_gather_runs(self, full, offs):
+    def _all_gather_runs(self, full, offs, wait=True):
+        """-> the requests still in flight (``wait=False`` on device tensors: the caller works beside the transfer and waits later)."""
         import torch
         import torch.distributed as dist
         r, W = self.rank, self.world
+        pending = []
         if self.on_device and self.p2p_gather:
             ops = []
             mine = full[offs[r]:offs[r + 1]]
@@ -210,12 +212,17 @@ class DistributedPangenes:
                 if offs[src + 1] > offs[src]:
                     ops.append(dist.P2POp(dist.irecv, full[offs[src]:offs[src + 1]], src))
             if ops:
-                for req in dist.batch_isend_irecv(ops):
-                    req.wait()
+                pending = list(dist.batch_isend_irecv(ops))
         elif self.on_device:                # PDL_DIST_GATHER=broadcast: one broadcast per run, in place (no point-to-point calls)
             for p in range(W):
                 if offs[p + 1] > offs[p]:
-                    dist.broadcast(full[offs[p]:offs[p + 1]], src=p)
+                    pending.append(dist.broadcast(full[offs[p]:offs[p + 1]], src=p, async_op=True))
+        if self.on_device:
+            if wait:
+                for req in pending:
+                    req.wait()
+                pending = []
+            return pending
         else:
             host = torch.empty(int(offs[-1]), dtype=torch.int64)
             host[offs[r]:offs[r + 1]] = full[offs[r]:offs[r + 1]].cpu()
@@ -223,6 +230,7 @@ class DistributedPangenes:
                 if offs[p + 1] > offs[p]:
                     dist.broadcast(host[offs[p]:offs[p + 1]], src=p)
             full.copy_(host)
+        return []
 
     def _all_to_all_rows(self, recv, send, recv_counts, send_counts):
         """Variable-size all-to-all of the rows of two device tensors (host-staged without device collectives)."""
@@ -303,13 +311,21 @@ class DistributedPangenes:
             nat.copy_device(full.data_ptr() + int(offs[r]) * 8, ptr, records * 8)
         with ExchangeDeadline("dictionary: runs gathered in place (" + ("point-to-point" if self.on_device and self.p2p_gather else "broadcasts") + ")", r, W,
                               "sending %d bytes to each peer; receiving %s bytes" % (records * 8, ", ".join(f"{int(offs[p + 1] - offs[p]) * 8} from rank {p}" for p in range(W) if p != r))):
-            self._all_gather_runs(full, offs)
-            self._sync()
+            if made is not None:
+                # the owners' finish sorts the tuples and only NOTES where the dictionary is: the runs travel beside it
+                pending = self._all_gather_runs(full, offs, wait=False)
+                t1 = time.perf_counter()
+                nat.dist_preprocess_finish_ranges(full.data_ptr(), total, recv_k.data_ptr(), recv_r.data_ptr(), n_in, sums,
+                                                  keepalive=(full, recv_k, recv_r))
+                t0 += time.perf_counter() - t1          # (the library call is not exchange time)
+                for req in pending:
+                    req.wait()
+                self._sync()
+            else:
+                self._all_gather_runs(full, offs)
+                self._sync()
         self.exchange_s["dictionary"] += time.perf_counter() - t0
-        if made is not None:
-            nat.dist_preprocess_finish_ranges(full.data_ptr(), total, recv_k.data_ptr(), recv_r.data_ptr(), n_in, sums,
-                                              keepalive=(full, recv_k, recv_r))
-        else:
+        if made is None:
             nat.dist_preprocess_finish(full.data_ptr(), total, genome_weights=weights, keepalive=full)
         return nat.cost
 

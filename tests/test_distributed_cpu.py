@@ -117,13 +117,15 @@ class _FakeRank:
 
     def dist_preprocess_finish_ranges(self, ptr, total, d_keys, d_ranges, n_tuples, counter_sums, keepalive=None):
         full, rk, rr = keepalive
-        self.seen["dictionary"] = full.clone()
+        self._full = full                        # (the runs may still be on their way: this call must not read the dictionary)
         self.seen["total"] = total
         self.seen["tuples"] = (rk[:n_tuples].tolist(), rr[:n_tuples].tolist())
         self.seen["sums"] = [int(x) for x in counter_sums]
         self.seen["flow"] = "sender"
 
     def dist_score_begin(self, world):
+        if getattr(self, "_full", None) is not None:
+            self.seen["dictionary"] = self._full.clone()
         return self.outbox.data_ptr(), self.counts
 
     def dist_score_finish(self, ptr, n, keepalive=None):

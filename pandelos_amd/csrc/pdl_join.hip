@@ -391,7 +391,6 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : (FILTER && T_ 
         if (ch >= ch_end) return;
         const uint2 ws = s_wstart[wave];
         uint32_t rs = __builtin_amdgcn_readfirstlane(ws.x);        // wave-uniform: range holding lookup ch * 64
-        uint32_t cum_rs = __builtin_amdgcn_readfirstlane(ws.y);    // and its first flat index
         for (; ch < ch_end; ch += NCH) {
             if (*(volatile uint32_t *) &s_overflow) break;
             uint2 gm[NCH], po[NCH];
@@ -409,13 +408,13 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : (FILTER && T_ 
                     if (u < nu) {                                        // wave-uniform
                         const uint32_t lo = f_lo + u * PDL_WAVE, f = lo + lane;
                         const uint32_t cu = (uint32_t) __popcll(__ballot(vw <= lo));       // ranges that begin at or before the chunk
-                        const uint32_t start_u = cu ? __builtin_amdgcn_readlane(vw, cu - 1) : cum_rs;
                         const bool inside = vw > lo && vw < lo + PDL_WAVE;
                         const int recv = __builtin_amdgcn_ds_permute((int) ((inside ? vw - lo : 0u) << 2), inside ? 1 : 0);
                         const unsigned long long m = __ballot(recv != 0);
-                        const unsigned long long below = m & ((2ull << lane) - 1ull);
-                        const uint32_t r = rs + cu + (uint32_t) __popcll(below);
-                        const uint32_t off = below ? lane - (63u - (uint32_t) __clzll((long long) below)) : f - start_u;
+                        // ranges that start at or before this lane's lookup: those up to the chunk's first one, the starts below the lane
+                        // (mbcnt), its own; the offset inside the range from the range's start (one more LDS read, no scan of the mask)
+                        const uint32_t r = rs + cu + __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u)) + (uint32_t) (recv != 0);
+                        const uint32_t off = f - s_cum[r];
                         live[u] = f < total;
                         gm[u] = s_gm[r];
                         adr[u] = gm[u].x + off;
@@ -426,7 +425,7 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : (FILTER && T_ 
                     }
                 }
                 const uint32_t ce = (uint32_t) __popcll(__ballot(vw <= f_hi));             // range holding the next iteration's first lookup
-                if (ce) { cum_rs = __builtin_amdgcn_readlane(vw, ce - 1); rs += ce; }
+                rs += ce;
             } else {
 #pragma unroll
             for (uint32_t u = 0; u < NCH; u++) {
@@ -440,9 +439,8 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : (FILTER && T_ 
                     const int recv = __builtin_amdgcn_ds_permute((int) ((inside ? v - f0 : 0u) << 2), inside ? 1 : 0);
                     const unsigned long long m = __ballot(recv != 0);
                     const uint32_t w = (uint32_t) __popcll(__ballot(inside));
-                    const unsigned long long below = m & ((2ull << lane) - 1ull);
-                    const uint32_t r = rs + (uint32_t) __popcll(below);
-                    const uint32_t off = below ? lane - (63u - (uint32_t) __clzll((long long) below)) : f - cum_rs;
+                    const uint32_t r = rs + __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u)) + (uint32_t) (recv != 0);
+                    const uint32_t off = f - s_cum[r];
                     live[u] = f < total;
                     gm[u] = s_gm[r];
                     adr[u] = gm[u].x + off;
@@ -452,8 +450,7 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : (FILTER && T_ 
 #endif
                     // keep the invariant "rs holds the first lookup of the next chunk": a range may start exactly there
                     const uint32_t nextb = w < PDL_WAVE ? __builtin_amdgcn_readlane(v, w) : s_cum[rs + 1 + PDL_WAVE];
-                    if (nextb == f0 + PDL_WAVE) { rs += w + 1; cum_rs = nextb; }
-                    else if (w) { cum_rs = __builtin_amdgcn_readlane(v, w - 1); rs += w; }
+                    rs += w + (uint32_t) (nextb == f0 + PDL_WAVE);
                 }
             }
             }

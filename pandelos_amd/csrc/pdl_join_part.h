@@ -47,12 +47,24 @@ constexpr uint32_t PT_BM_SHIFT = 22 - PT_BM_BITS;        // word = h >> PT_BM_SH
 constexpr uint32_t PT_HT_BITS = 10, PT_HT = 1u << PT_HT_BITS;
 constexpr uint32_t PT_WLIST = (PT_BM_WORDS + PT_RB + 66) / PT_NW;       // surviving keys a wave can list
 constexpr uint32_t PT_BATCH = 8;                         // rows a workgroup draws from the dispenser at a time
-constexpr uint32_t PT_HASH_MUL = 0x9E3779B1u;
+// h(c) = c * M mod 2^22 with M = 0x9E3779B1 mod 2^22: only the low 22 bits of the multiplier matter, so the product is that of two
+// 24-bit values and v_mul_u32_u24 — a full-rate instruction, where v_mul_lo_u32 takes four times as long — gives the same hash.
+// (The multiplier matters: 0x9E3779 in its place slowed the whole join by a quarter — homologs' gene ids are regularly spaced,
+// and their bits in the two bitmaps collided.)
+constexpr uint32_t PT_HASH_MUL = 0x9E3779B1u & 0x3fffffu;
 constexpr uint32_t pt_inverse(uint32_t m) { uint32_t x = m; for (int i = 0; i < 5; i++) x *= 2u - m * x; return x; }
 constexpr uint32_t PT_HASH_INV = pt_inverse(PT_HASH_MUL);
 static_assert((uint32_t) (PT_HASH_MUL * PT_HASH_INV) == 1u, "multiplicative inverse mod 2^32 (hence mod 2^22)");
 constexpr uint32_t PT_TOUCH_CAP = (3 * PT_HT) / 4 + PT_T;        // every row's part of the table takes keys until it is three quarters full (+ one per thread in flight)
 static_assert(PT_RB <= 1022 && PT_RB % PDL_WAVE == 0 && PT_TOUCH_CAP <= CELL_CHUNK, "10-bit range index");
+
+// low 32 bits of the product of two 24-bit values, in ONE full-rate instruction (the compiler sees through __umul24 once the result is
+// masked — the low bits of a product do not depend on the high bits of its factors — and falls back to the quarter-rate v_mul_lo_u32)
+__device__ __forceinline__ uint32_t pt_mul_u24(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 struct PartRow { uint32_t p, r, kcnt, genome, lg, pc_min, pad0, pad1; };
 
@@ -263,7 +275,6 @@ __global__ __launch_bounds__(PT_T, PT_WG_PER_CU) void k_join_part(JoinArgs a) {
             const uint32_t ch_end = min(chunks, ch + cpw);
             const uint2 ws = s_wstart[wave];
             uint32_t rs = (uint32_t) __builtin_amdgcn_readfirstlane((int) ws.x);
-            uint32_t cum_rs = (uint32_t) __builtin_amdgcn_readfirstlane((int) ws.y);
 #pragma unroll
             for (uint32_t it = 0; it < PT_ITERS; it++) {
                 if (ch < ch_end) {                           // (wave-uniform)
@@ -281,23 +292,23 @@ __global__ __launch_bounds__(PT_T, PT_WG_PER_CU) void k_join_part(JoinArgs a) {
                             if (u < nu) {
                                 const uint32_t lo = f_lo + u * PDL_WAVE, f = lo + lane;
                                 const uint32_t cu = (uint32_t) __popcll(__ballot(vw <= lo));
-                                const uint32_t start_u = cu ? (uint32_t) __builtin_amdgcn_readlane((int) vw, cu - 1) : cum_rs;
                                 const bool inside = vw > lo && vw < lo + PDL_WAVE;
                                 const int recv = __builtin_amdgcn_ds_permute((int) ((inside ? vw - lo : 0u) << 2), inside ? 1 : 0);
                                 const unsigned long long m = __ballot(recv != 0);
-                                const unsigned long long below = m & ((2ull << lane) - 1ull);
-                                const uint32_t r = rs + cu + (uint32_t) __popcll(below);
-                                const uint32_t off = below ? lane - (63u - (uint32_t) __clzll((long long) below)) : f - start_u;
+                                // ranges that start at or before this lane's lookup: those up to the chunk's first one, the starts below the lane (mbcnt), its own
+                                const uint32_t r = rs + cu + __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u)) + (uint32_t) (recv != 0);
                                 live[u] = f < total;
                                 const uint32_t rl = live[u] ? r : 0u;
                                 const uint2 gmu = s_gm[rl];
+                                const uint32_t cum_r = s_cum[rl];                // where range rl starts in the row's lookups: one LDS read instead of a scan of the mask
                                 key[it * PT_NCH + u] = rl;
-                                adr[u] = gmu.x + off;
+                                adr[u] = gmu.x + (f - cum_r);
+
                                 ownhv |= (uint32_t) ((gmu.y >> 22) >= 2u) << u;
                             }
                         }
                         const uint32_t ce = (uint32_t) __popcll(__ballot(vw <= f_hi));
-                        if (ce) { cum_rs = (uint32_t) __builtin_amdgcn_readlane((int) vw, ce - 1); rs += ce; }
+                        rs += ce;
                     } else {
 #pragma unroll
                         for (uint32_t u = 0; u < PT_NCH; u++) {
@@ -309,18 +320,16 @@ __global__ __launch_bounds__(PT_T, PT_WG_PER_CU) void k_join_part(JoinArgs a) {
                                 const int recv = __builtin_amdgcn_ds_permute((int) ((inside ? v - f0 : 0u) << 2), inside ? 1 : 0);
                                 const unsigned long long m = __ballot(recv != 0);
                                 const uint32_t w = (uint32_t) __popcll(__ballot(inside));
-                                const unsigned long long below = m & ((2ull << lane) - 1ull);
-                                const uint32_t r = rs + (uint32_t) __popcll(below);
-                                const uint32_t off = below ? lane - (63u - (uint32_t) __clzll((long long) below)) : f - cum_rs;
+                                const uint32_t r = rs + __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u)) + (uint32_t) (recv != 0);
                                 live[u] = f < total;
                                 const uint32_t rl = live[u] ? r : 0u;
                                 const uint2 gmu = s_gm[rl];
+                                const uint32_t cum_r = s_cum[rl];
                                 key[it * PT_NCH + u] = rl;
-                                adr[u] = gmu.x + off;
+                                adr[u] = gmu.x + (f - cum_r);
                                 ownhv |= (uint32_t) ((gmu.y >> 22) >= 2u) << u;
                                 const uint32_t nextb = w < PDL_WAVE ? (uint32_t) __builtin_amdgcn_readlane((int) v, w) : s_cum[rs + 1 + PDL_WAVE];
-                                if (nextb == f0 + PDL_WAVE) { rs += w + 1; cum_rs = nextb; }
-                                else if (w) { cum_rs = (uint32_t) __builtin_amdgcn_readlane((int) v, w - 1); rs += w; }
+                                rs += w + (uint32_t) (nextb == f0 + PDL_WAVE);          // (a range that starts with the next chunk is that chunk's first)
                             }
                         }
                     }
@@ -329,7 +338,7 @@ __global__ __launch_bounds__(PT_T, PT_WG_PER_CU) void k_join_part(JoinArgs a) {
                     uint32_t seen[PT_NCH], bit[PT_NCH], wd[PT_NCH];
 #pragma unroll
                     for (uint32_t u = 0; u < PT_NCH; u++) {          // four bitmap atomics in flight
-                        const uint32_t h = (po[u].x * PT_HASH_MUL) & 0x3fffffu;
+                                                const uint32_t h = pt_mul_u24(po[u].x, PT_HASH_MUL) & 0x3fffffu;      // (gene ids have 22 bits here)
                         key[it * PT_NCH + u] |= h << 10;
                         wd[u] = h >> PT_BM_SHIFT; bit[u] = 1u << ((h >> (PT_BM_SHIFT - 5)) & 31u);        // (the column alone: a column two rows of the cycle meet once each survives the sift and is told apart later)
                         seen[u] = live[u] ? atomicOr(&s_bm1[wd[u]], bit[u]) : 0u;
@@ -434,7 +443,7 @@ __global__ __launch_bounds__(PT_T, PT_WG_PER_CU) void k_join_part(JoinArgs a) {
             }
             const uint32_t inter = light + s_min, pcn = light + s_own, tcn = light + s_cc;
             const PartRow row = s_row[sl];
-            const uint32_t c = (hk * PT_HASH_INV) & 0x3fffffu;
+            const uint32_t c = (hk * PT_HASH_INV) & 0x3fffffu;      // (the inverse mod 2^22 is all a 22-bit product needs)
             if (c >= a.N) { atomicAdd(a.error_count, 1u); continue; }
             if (c == row.r) continue;                        // identity cell is zeroed (library.cpp:485-487)
             if (pcn < row.pc_min && tcn < tc_min) continue;  // cannot be valid (see k_join_lds): among them every column sighted once

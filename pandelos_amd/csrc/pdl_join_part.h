@@ -338,7 +338,7 @@ __global__ __launch_bounds__(PT_T, PT_WG_PER_CU) void k_join_part(JoinArgs a) {
                     uint32_t seen[PT_NCH], bit[PT_NCH], wd[PT_NCH];
 #pragma unroll
                     for (uint32_t u = 0; u < PT_NCH; u++) {          // four bitmap atomics in flight
-                                                const uint32_t h = pt_mul_u24(po[u].x, PT_HASH_MUL) & 0x3fffffu;      // (gene ids have 22 bits here)
+                        const uint32_t h = pt_mul_u24(po[u].x, PT_HASH_MUL) & 0x3fffffu;      // (gene ids have 22 bits here)
                         key[it * PT_NCH + u] |= h << 10;
                         wd[u] = h >> PT_BM_SHIFT; bit[u] = 1u << ((h >> (PT_BM_SHIFT - 5)) & 31u);        // (the column alone: a column two rows of the cycle meet once each survives the sift and is told apart later)
                         seen[u] = live[u] ? atomicOr(&s_bm1[wd[u]], bit[u]) : 0u;

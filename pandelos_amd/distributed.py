@@ -131,41 +131,75 @@ def device_view(ptr: int, shape, dtype, device):
 
 
 # ---- a deadline for every exchange --------------------------------------------------------------------------------
+class _Watchdog:
+    """ONE daemon thread per process looks after every exchange that is under way (a timer thread per exchange cost ~0.1 ms of
+    thread start-up each, five times per step)."""
+
+    def __init__(self):
+        import threading
+        self.lock = threading.Lock()
+        self.open = {}                   # id -> (expiry on the monotonic clock, ExchangeDeadline)
+        self.thread = None
+
+    def _run(self):
+        import time
+        while True:
+            time.sleep(0.2)
+            now = time.monotonic()
+            with self.lock:
+                late = [d for (t, d) in self.open.values() if t <= now]
+            if late:
+                late[0]._expired()
+
+    def add(self, deadline):
+        import threading
+        import time
+        with self.lock:
+            self.open[id(deadline)] = (time.monotonic() + deadline.seconds, deadline)
+            if self.thread is None:
+                self.thread = threading.Thread(target=self._run, name="pandelos-exchange-watchdog", daemon=True)
+                self.thread.start()
+
+    def remove(self, deadline):
+        with self.lock:
+            self.open.pop(id(deadline), None)
+
+
+_watchdog = _Watchdog()
+
+
 class ExchangeDeadline:
     """``with ExchangeDeadline(...)`` around a blocking exchange: a rank whose exchange has not completed in ``seconds`` says
     which exchange, with which peers and how many bytes, and EXITS NON-ZERO (``os._exit``: the main thread sits inside the
     collective and cannot be unwound; the launcher then tears the job down instead of waiting for its own limit).  A fresh
     launch may set ``PDL_DIST_GATHER=broadcast`` to swap the point-to-point gather for broadcasts.  ``PDL_DIST_TIMEOUT_S``
-    sets the deadline (default 120 s, 0 = none)."""
+    sets the deadline (default 120 s, 0 = none).  ``detail`` may be a callable: the text is only made when it is needed."""
 
     EXIT_CODE = 87
 
-    def __init__(self, what: str, rank: int, world: int, detail: str = "", seconds: float = None):
+    def __init__(self, what: str, rank: int, world: int, detail="", seconds: float = None):
         import os
         self.what, self.rank, self.world, self.detail = what, rank, world, detail
         self.seconds = float(os.environ.get("PDL_DIST_TIMEOUT_S", "120")) if seconds is None else float(seconds)
-        self.timer = None
 
     def _expired(self):
         import os
         import sys
+        detail = self.detail() if callable(self.detail) else self.detail
         sys.stderr.write(f"pandelos_amd: rank {self.rank} of {self.world}: exchange '{self.what}' has not completed in "
-                         f"{self.seconds:g} s ({self.detail}); giving up (exit {self.EXIT_CODE}).  "
+                         f"{self.seconds:g} s ({detail}); giving up (exit {self.EXIT_CODE}).  "
                          f"A fresh launch may set PDL_DIST_GATHER=broadcast for the dictionary gather.\n")
         sys.stderr.flush()
         os._exit(self.EXIT_CODE)
 
     def __enter__(self):
         if self.seconds > 0:
-            import threading
-            self.timer = threading.Timer(self.seconds, self._expired)
-            self.timer.daemon = True
-            self.timer.start()
+            _watchdog.add(self)
         return self
 
     def __exit__(self, *exc):
-        if self.timer is not None:
-            self.timer.cancel()
+        if self.seconds > 0:
+            _watchdog.remove(self)
         return False
 
 
@@ -233,19 +267,31 @@ class DistributedPangenes:
         return []
 
     def _all_to_all_rows(self, recv, send, recv_counts, send_counts):
-        """Variable-size all-to-all of the rows of two device tensors (host-staged without device collectives)."""
+        """Variable-size all-to-all of the rows of two device tensors (host-staged without device collectives).  What a rank
+        files for itself does not go through the collective: RCCL moves a self-addressed chunk at a fraction of a device copy's
+        rate (a group of one: 31 GB/s), so it is copied; two calls carry the rest: first every rank's rows for the ranks below it, then those
+        for the ranks above it (each call's input and output are then contiguous stretches)."""
         import torch
         import torch.distributed as dist
-        n_in, n_out = int(np.sum(recv_counts)), int(np.sum(send_counts))
+        r, W = self.rank, self.world
         rs, ss = [int(x) for x in recv_counts], [int(x) for x in send_counts]
-        if self.on_device:
-            dist.all_to_all_single(recv[:n_in], send[:n_out], output_split_sizes=rs, input_split_sizes=ss)
-        else:
+        n_in, n_out = sum(rs), sum(ss)
+        if not self.on_device:
             h_recv = torch.empty((n_in,) + tuple(recv.shape[1:]), dtype=recv.dtype)
             dist.all_to_all_single(h_recv, send[:n_out].cpu(), output_split_sizes=rs, input_split_sizes=ss)
             recv[:n_in].copy_(h_recv)
             if getattr(self.dev, "type", "cpu") == "cuda":
                 torch.cuda.synchronize(self.dev)
+            return
+        if ss[r] != rs[r]:
+            raise RuntimeError(f"rank {r} files {ss[r]} rows for itself and expects {rs[r]}")
+        so, ro = sum(ss[:r]), sum(rs[:r])
+        if ss[r]:
+            recv[ro:ro + rs[r]].copy_(send[so:so + ss[r]])
+        zero = [0] * W
+        if W > 1:      # every rank makes both calls.  "down": what goes to lower ranks, i.e. arrives from higher ones; then "up"
+            dist.all_to_all_single(recv[ro + rs[r]:n_in], send[:so], output_split_sizes=zero[:r + 1] + rs[r + 1:], input_split_sizes=ss[:r] + zero[r:])
+            dist.all_to_all_single(recv[:ro], send[so + ss[r]:n_out], output_split_sizes=rs[:r] + zero[r:], input_split_sizes=zero[:r + 1] + ss[r + 1:])
 
     def preprocess(self, k, t_res, t_off, t_gen, n_genes, n_residues):
         import time
@@ -297,8 +343,8 @@ class DistributedPangenes:
                 if n_out:
                     nat.copy_device(send_k.data_ptr(), kptr, n_out * 4)
                     nat.copy_device(send_r.data_ptr(), rptr, n_out * 8)
-            detail = ("sending " + ", ".join(f"{int(c) * 12} to rank {d}" for d, c in enumerate(send_counts) if d != r) +
-                      " bytes; receiving " + ", ".join(f"{int(c) * 12} from rank {p}" for p, c in enumerate(recv_counts) if p != r) + " bytes")
+            detail = lambda: ("sending " + ", ".join(f"{int(c) * 12} to rank {d}" for d, c in enumerate(send_counts) if d != r) +
+                              " bytes; receiving " + ", ".join(f"{int(c) * 12} from rank {p}" for p, c in enumerate(recv_counts) if p != r) + " bytes")
             with ExchangeDeadline("ranges: 12-byte tuples (two all-to-alls: keys, packed ranges)", r, W, detail):
                 self._all_to_all_rows(recv_k, send_k, recv_counts, send_counts)
                 self._all_to_all_rows(recv_r, send_r, recv_counts, send_counts)
@@ -310,7 +356,7 @@ class DistributedPangenes:
         if records:
             nat.copy_device(full.data_ptr() + int(offs[r]) * 8, ptr, records * 8)
         with ExchangeDeadline("dictionary: runs gathered in place (" + ("point-to-point" if self.on_device and self.p2p_gather else "broadcasts") + ")", r, W,
-                              "sending %d bytes to each peer; receiving %s bytes" % (records * 8, ", ".join(f"{int(offs[p + 1] - offs[p]) * 8} from rank {p}" for p in range(W) if p != r))):
+                              lambda: "sending %d bytes to each peer; receiving %s bytes" % (records * 8, ", ".join(f"{int(offs[p + 1] - offs[p]) * 8} from rank {p}" for p in range(W) if p != r))):
             if made is not None:
                 # the owners' finish sorts the tuples and only NOTES where the dictionary is: the runs travel beside it
                 pending = self._all_gather_runs(full, offs, wait=False)
@@ -349,8 +395,8 @@ class DistributedPangenes:
             send = torch.empty((max(n_out, 1), 6), dtype=torch.int32, device=self.dev)
             if n_out:
                 nat.copy_device(send.data_ptr(), ptr, n_out * _lib.DIST_CELL_BYTES)
-        detail = ("sending " + ", ".join(f"{int(c) * _lib.DIST_CELL_BYTES} to rank {d}" for d, c in enumerate(send_counts) if d != self.rank) +
-                  " bytes; receiving " + ", ".join(f"{int(c) * _lib.DIST_CELL_BYTES} from rank {p}" for p, c in enumerate(recv_counts) if p != self.rank) + " bytes")
+        detail = lambda: ("sending " + ", ".join(f"{int(c) * _lib.DIST_CELL_BYTES} to rank {d}" for d, c in enumerate(send_counts) if d != self.rank) +
+                          " bytes; receiving " + ", ".join(f"{int(c) * _lib.DIST_CELL_BYTES} from rank {p}" for p, c in enumerate(recv_counts) if p != self.rank) + " bytes")
         with ExchangeDeadline("cells: 24-byte cells (all-to-all)", self.rank, W, detail):
             self._all_to_all_rows(recv, send, recv_counts, send_counts)
             self._sync()

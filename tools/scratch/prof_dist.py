@@ -34,9 +34,14 @@ def te(*a, **kw):
 torch.empty = te
 oag = dist.all_gather_into_tensor
 dist.all_gather_into_tensor = timed("all_gather_small", oag)
-for i in range(6):
+dp.nat.dist_score_begin = timed('lib_score_begin', dp.nat.dist_score_begin)
+dp.nat.dist_score_finish = timed('lib_score_finish', dp.nat.dist_score_finish)
+for i in range(8):
     acc.clear(); torch.cuda.synchronize(); t=time.perf_counter()
     dp.preprocess(k, t_res, t_off, t_gen, gs.genes, len(gs.residues)); torch.cuda.synchronize()
+    tp=time.perf_counter()-t
+    dp.score_all(); torch.cuda.synchronize()
     tot=time.perf_counter()-t
+    print("   preprocess %.2f ms score %.2f ms"%(tp*1e3,(tot-tp)*1e3))
     print(i, "total %.2f ms"%(tot*1e3), {n: round(v*1e3,3) for n,v in acc.items()}, {n: round(v*1e3,3) for n,v in dp.exchange_s.items()}, flush=True)
 dist.destroy_process_group()

@@ -228,7 +228,7 @@ struct pdl_ctx {
     DevBuf task_off;      // u32 [shard+1] task offsets | gathered cell offsets + 8 counters + cell total
     int cus = 0;
     uint32_t occ_tier1[5] = {0, 0, 0, 0, 0};
-    uint32_t occ_tier0 = 0;
+    uint32_t occ_tier0 = 0, occ_tier0b = 0;
 
     // K-bbh (pdl_bbh.hip): network edges of every genome task, on the host after the first pdl_compute_edges
     bool edges_valid = false;

@@ -1337,7 +1337,7 @@ __global__ void k_gather_u32(const uint32_t *src, const uint32_t *idx, uint32_t 
     else if (i < n + 8) dst[i] = ctr[i - n];
     else if (i < n + 10) dst[i] = z64[i - n - 8];
     else if (i == n + 10) dst[i] = ctr[10];          // entries of the put-aside lists that had to be loaded again
-    else if (i == n + 11) dst[i] = ctr[12];          // rows the partition tier handed to tier 1
+    else if (i == n + 11) dst[i] = ctr[14];          // rows the partition tier (both forms) handed to tier 1
 }
 
 // Clears up to four arrays in one launch (16-byte words; every separate small fill is a dispatch of its own).
@@ -1419,7 +1419,7 @@ __global__ void k_iota_u32(uint32_t *dst, uint32_t n) { uint32_t i = blockIdx.x 
 struct ScorePlan {
     bool wide, mirror;
     bool tier0;                    // the partition tier runs in front of tier 1 (short rows)
-    uint32_t grid0;
+    uint32_t grid0, grid0b;        // (the second form of the partition tier: 512 threads, the rows that alone exceed the first form's cycle)
     int tier1, occ_slot;
     bool tiny_tier2;
     uint32_t grid1, grid2, grid3;
@@ -1485,8 +1485,9 @@ static ScorePlan score_plan(pdl_ctx *c) {
         const bool want = c->opt_tier0 > 0 || (c->opt_tier0 < 0 && c->opt_tier1 < 0 && n_rows >= 12288 && walked / n_rows <= 3000 && c->Urepeat * 5000 <= c->U);      // (fewer rows: the extra launches cost more than the tier saves)
         pl.tier0 = can && want;
         if (pl.tier0) {
-            if (c->occ_tier0 == 0) c->occ_tier0 = occupancy((const void *) k_join_part, (int) PT_T);
+            if (c->occ_tier0 == 0) { c->occ_tier0 = occupancy((const void *) k_join_part<PT_T, PT_WG_PER_CU>, (int) PT_T); c->occ_tier0b = occupancy((const void *) k_join_part<PT_T2, PT_WGS2>, (int) PT_T2); }
             pl.grid0 = std::min<uint32_t>((n_rows + PT_BATCH - 1) / PT_BATCH, (uint32_t) cus * c->occ_tier0);
+            pl.grid0b = std::min<uint32_t>(n_rows, (uint32_t) cus * c->occ_tier0b);
             if (c->opt_grid_pct > 0) pl.grid0 = std::max<uint32_t>(1, (uint32_t) ((uint64_t) pl.grid0 * (uint32_t) c->opt_grid_pct / 100));
         }
     }
@@ -1506,7 +1507,7 @@ static ScorePlan score_plan(pdl_ctx *c) {
         c->glb_clean = true;
     }
     // Every workgroup reserves staging in chunks of CELL_CHUNK cells: a partly used chunk per workgroup of every tier
-    pl.slack = 2ull * (pl.grid0 + pl.grid1 + pl.grid2 + pl.grid3) * CELL_CHUNK;
+    pl.slack = 2ull * (pl.grid0 + pl.grid0b + pl.grid1 + pl.grid2 + pl.grid3) * CELL_CHUNK;
     return pl;
 }
 
@@ -1519,8 +1520,8 @@ static void score_alloc_rows(pdl_ctx *c, const ScorePlan &pl) {
     c->row_base.alloc((size_t) n_rows * 4); c->row_cnt.alloc((size_t) n_rows * 4); c->fin_off.alloc(((size_t) n_rows + 2) * 4);      // (+1: the scan stores its 64-bit total at [n_rows])
     c->join_ctr.alloc(64);
     c->row_desc.alloc((size_t) n_rows * sizeof(uint4));
-    c->row_desc2.alloc((size_t) n_rows * sizeof(uint4) * (pl.tier0 ? 2 : 1));      // descriptors of the rows a tier handed on (tier 0 -> 1 | tier 1 -> 2)
-    c->overflow_rows.alloc((size_t) n_rows * 4 * 3);     // list A (tier 1 -> 2), list B (tier 2 -> 3), list S (tier 0 -> 1)
+    c->row_desc2.alloc((size_t) n_rows * sizeof(uint4) * (pl.tier0 ? 3 : 1));      // descriptors of the rows a tier handed on (tier 1 -> 2 | tier 0 -> its second form | that -> 1)
+    c->overflow_rows.alloc((size_t) n_rows * 4 * 4);     // list A (tier 1 -> 2), list B (tier 2 -> 3), list S (tier 0 -> its second form), list S2 (that -> tier 1)
     if (pl.mirror) c->mirror_cnt.alloc((size_t) n_rows * 4 * 3 + 16);    // counts | offsets | cursors
     c->gene_info.alloc((size_t) N * sizeof(uint4));
     hipLaunchKernelGGL(k_row_desc, dim3((std::max(n_rows, N) + 255) / 256), dim3(256), 0, c->stream, c->task_rows.as<uint32_t>(), c->seq_off.as<uint32_t>(),
@@ -1578,9 +1579,9 @@ static void score_join(pdl_ctx *c, const ScorePlan &pl) {
     }
     JoinArgs a = join_args(c, pl);
     // counters: 0 cursor tier 1 | 1 rows for tier 2 | 2 cursor tier 2 | 3 rows for tier 3 | 4-5 cell cursor | 6 errors | 7 cursor tier 3 | 9 wide rows seen by K-order
-    //           | 10 put-aside entries loaded again | 11 cursor tier 0 | 12 rows tier 0 handed to tier 1
+    //           | 10 put-aside entries loaded again | 11 cursor tier 0 | 12 rows tier 0 handed to its second form | 13 cursor of that | 14 rows it handed to tier 1
     uint32_t *ctr32 = c->join_ctr.as<uint32_t>();
-    uint32_t *list_a = c->overflow_rows.as<uint32_t>(), *list_b = list_a + n_rows, *list_s = list_b + n_rows;
+    uint32_t *list_a = c->overflow_rows.as<uint32_t>(), *list_b = list_a + n_rows, *list_s = list_b + n_rows, *list_s2 = list_s + n_rows;
     a.error_count = ctr32 + 6; a.reload_count = ctr32 + 10;
     a.cell_cursor = reinterpret_cast<unsigned long long *>(ctr32 + 4);
 
@@ -1593,11 +1594,18 @@ static void score_join(pdl_ctx *c, const ScorePlan &pl) {
     a.work = nullptr; a.desc = c->row_desc.as<uint4>(); a.n_work = pl.wide ? 0 : n_rows; a.n_work_ptr = nullptr;
     if (pl.tier0) {
         a.work_cursor = ctr32 + 11; a.overflow_count = ctr32 + 12; a.overflow_rows = list_s; a.work_batch = PT_BATCH;
-        hipLaunchKernelGGL(k_join_part, dim3(pl.grid0), dim3(PT_T), 0, st, a);
+        hipLaunchKernelGGL((k_join_part<PT_T, PT_WG_PER_CU>), dim3(pl.grid0), dim3(PT_T), 0, st, a);
+        // ... its second form (512 threads: twice the lookups per cycle) over the rows that alone exceed the first form's cycle,
+        // one row per draw; what that cannot hold either is listed for tier 1
         hipLaunchKernelGGL(k_row_desc_list, dim3((n_rows + 255) / 256), dim3(256), 0, st, list_s, ctr32 + 12, c->task_rows.as<uint32_t>(),
                            c->seq_off.as<uint32_t>(), c->row_desc2.as<uint4>() + n_rows);
         a.desc = c->row_desc2.as<uint4>() + n_rows; a.n_work = 0; a.n_work_ptr = ctr32 + 12;
-        c->tm.join_launches += 1;
+        a.work_cursor = ctr32 + 13; a.overflow_count = ctr32 + 14; a.overflow_rows = list_s2; a.work_batch = 1;
+        hipLaunchKernelGGL((k_join_part<PT_T2, PT_WGS2>), dim3(pl.grid0b), dim3(PT_T2), 0, st, a);
+        hipLaunchKernelGGL(k_row_desc_list, dim3((n_rows + 255) / 256), dim3(256), 0, st, list_s2, ctr32 + 14, c->task_rows.as<uint32_t>(),
+                           c->seq_off.as<uint32_t>(), c->row_desc2.as<uint4>() + 2 * (size_t) n_rows);
+        a.desc = c->row_desc2.as<uint4>() + 2 * (size_t) n_rows; a.n_work = 0; a.n_work_ptr = ctr32 + 14;
+        c->tm.join_launches += 2;
     }
     // tier 1
     a.work_cursor = ctr32 + 0; a.overflow_count = ctr32 + 1; a.overflow_rows = list_a;

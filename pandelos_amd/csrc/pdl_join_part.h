@@ -31,21 +31,19 @@
 // <= 2k k-mers, too many columns or heavy lookups) go to the filter tier through the usual device-side list.
 #pragma once
 
-constexpr uint32_t PT_T = 256, PT_NW = PT_T / PDL_WAVE;
+constexpr uint32_t PT_T = 256;                           // threads of the kernel's first form (the second, for the rows that exceed its cycle, has PT_T2)
+constexpr uint32_t PT_T2 = 512, PT_WGS2 = 3;             // (85 registers: three workgroups of eight waves per CU)
 constexpr uint32_t PT_RB = 960;                          // ranges staged per cycle (10-bit range index in a key)
-constexpr uint32_t PT_RPT = 4;                           // ranges per thread in the staging loops (threads beyond RB / RPT idle)
 constexpr uint32_t PT_ROWS = 4;                          // rows per cycle
 #ifndef PT_WG_PER_CU
 #define PT_WG_PER_CU 5
 #endif
 constexpr uint32_t PT_NCH = 4, PT_ITERS = PT_WG_PER_CU >= 5 ? 4 : 6;      // chunks of 64 lookups in flight per wave, steps per wave
 constexpr uint32_t PT_KPT = PT_NCH * PT_ITERS;           // keys a lane holds between the walk and the sift
-constexpr uint32_t PT_LMAX = PT_KPT * PT_T;              // 4096 lookups per cycle
 constexpr uint32_t PT_HEAVY_CAP = 64;                    // lookups with a count >= 2 per cycle
 constexpr uint32_t PT_BM_BITS = PT_WG_PER_CU >= 5 ? 10 : 11, PT_BM_WORDS = 1u << PT_BM_BITS;      // each bitmap: 32 Kbit (64 with four workgroups per CU)
 constexpr uint32_t PT_BM_SHIFT = 22 - PT_BM_BITS;        // word = h >> PT_BM_SHIFT, bit = the five bits below
 constexpr uint32_t PT_HT_BITS = 10, PT_HT = 1u << PT_HT_BITS;
-constexpr uint32_t PT_WLIST = (PT_BM_WORDS + PT_RB + 66) / PT_NW;       // surviving keys a wave can list
 constexpr uint32_t PT_BATCH = 8;                         // rows a workgroup draws from the dispenser at a time
 // h(c) = c * M mod 2^22 with M = 0x9E3779B1 mod 2^22: only the low 22 bits of the multiplier matter, so the product is that of two
 // 24-bit values and v_mul_u32_u24 — a full-rate instruction, where v_mul_lo_u32 takes four times as long — gives the same hash.
@@ -55,8 +53,7 @@ constexpr uint32_t PT_HASH_MUL = 0x9E3779B1u & 0x3fffffu;
 constexpr uint32_t pt_inverse(uint32_t m) { uint32_t x = m; for (int i = 0; i < 5; i++) x *= 2u - m * x; return x; }
 constexpr uint32_t PT_HASH_INV = pt_inverse(PT_HASH_MUL);
 static_assert((uint32_t) (PT_HASH_MUL * PT_HASH_INV) == 1u, "multiplicative inverse mod 2^32 (hence mod 2^22)");
-constexpr uint32_t PT_TOUCH_CAP = (3 * PT_HT) / 4 + PT_T;        // every row's part of the table takes keys until it is three quarters full (+ one per thread in flight)
-static_assert(PT_RB <= 1022 && PT_RB % PDL_WAVE == 0 && PT_TOUCH_CAP <= CELL_CHUNK, "10-bit range index");
+static_assert(PT_RB <= 1022 && PT_RB % PDL_WAVE == 0 && (3 * PT_HT) / 4 + PT_T2 <= CELL_CHUNK, "10-bit range index");
 
 // low 32 bits of the product of two 24-bit values, in ONE full-rate instruction (the compiler sees through __umul24 once the result is
 // masked — the low bits of a product do not depend on the high bits of its factors — and falls back to the quarter-rate v_mul_lo_u32)
@@ -68,7 +65,17 @@ __device__ __forceinline__ uint32_t pt_mul_u24(uint32_t a, uint32_t b) {
 
 struct PartRow { uint32_t p, r, kcnt, genome, lg, pc_min, pad0, pad1; };
 
-__global__ __launch_bounds__(PT_T, PT_WG_PER_CU) void k_join_part(JoinArgs a) {
+// TT threads: 256 (five workgroups per CU, a cycle of 4096 lookups) — every row goes through this form first — or 512 (a cycle of
+// 8192 lookups, for the rows the first form hands on because they alone exceed its cycle: on the 64-genome set 923 rows of
+// 4100-7200 lookups, which the filter tier used to take one per workgroup, a launch as long as its longest row)
+template <uint32_t TT, uint32_t WGS>
+__global__ __launch_bounds__(TT, WGS) void k_join_part(JoinArgs a) {
+    constexpr uint32_t PT_T = TT, PT_NW = PT_T / PDL_WAVE;
+    constexpr uint32_t PT_RPT = (PT_RB + PT_T - 1) / PT_T;              // ranges per thread in the staging loops
+    constexpr uint32_t PT_LMAX = PT_KPT * PT_T;                         // lookups per cycle
+    constexpr uint32_t PT_WLIST = (PT_BM_WORDS + PT_RB + 66) / PT_NW;   // surviving keys a wave can list
+    constexpr uint32_t PT_TOUCH_CAP = (3 * PT_HT) / 4 + PT_T;           // every row's part of the table takes keys until it is three quarters full (+ one per thread in flight)
+    static_assert(PT_WLIST >= PT_NCH * PDL_WAVE, "a wave's list holds at least one round of survivors");
     __shared__ uint32_t s_big[2 * PT_BM_WORDS + PT_RB + 66];   // "seen twice" | "seen" | prefix of the staged ranges' lengths; once the walk is
                                                                // over the last two are one stretch: every wave's list of surviving keys
     __shared__ uint32_t s_tkey[PT_HT];                   // table: smallest key + 1 that reached the slot (0: empty)
@@ -87,6 +94,7 @@ __global__ __launch_bounds__(PT_T, PT_WG_PER_CU) void k_join_part(JoinArgs a) {
     const uint32_t tid = threadIdx.x, lane = tid & (PDL_WAVE - 1), wave = tid / PDL_WAVE;
     const uint32_t n_work = a.n_work_ptr ? *a.n_work_ptr : a.n_work;
     if (n_work == 0) return;
+    const uint32_t batch = min(max(a.work_batch, 1u), PT_BATCH);       // rows a workgroup draws at a time (one, for the few long rows of the second form)
     uint32_t *s_bm2 = s_big, *s_bm1 = s_big + PT_BM_WORDS, *s_cum = s_big + 2 * PT_BM_WORDS;
     for (uint32_t i = tid; i < PT_HT; i += PT_T) { s_tkey[i] = 0; s_tn[i] = 0; }      // cleared once; afterwards every slot is reset by whoever consumes it
     if (tid == 0) { s_nheavy = 0; s_ntouched = 0; s_overflow = 0; s_solo = 0; s_bn = 0; s_bpos = 0; s_chunk_next = 0; s_chunk_end = 0; }
@@ -100,16 +108,16 @@ __global__ __launch_bounds__(PT_T, PT_WG_PER_CU) void k_join_part(JoinArgs a) {
         pdl_sync();
         // ---- rows: a batch of consecutive work items at a time -------------------------------------------------------
         if (s_bpos >= s_bn) {                                // (uniform) batch used up: draw the next one
-            if (tid == 0) s_w0 = atomicAdd(a.work_cursor, PT_BATCH);
+            if (tid == 0) s_w0 = atomicAdd(a.work_cursor, batch);
             pdl_sync();
             const uint32_t w0 = s_w0;
             if (w0 >= n_work) break;                         // (uniform) every wave leaves here
-            if (tid < PT_BATCH && w0 + tid < n_work) {
+            if (tid < batch && w0 + tid < n_work) {
                 const uint4 d = a.desc[w0 + tid];            // {task position, gene, first range, ranges}
                 s_bdesc[tid] = d;
                 s_binfo[tid] = a.gene_info[d.y];             // {k-mers, genome, task position, shard-local genome}
             }
-            if (tid == 0) { s_bn = min((uint32_t) PT_BATCH, n_work - w0); s_bpos = 0; }
+            if (tid == 0) { s_bn = min(batch, n_work - w0); s_bpos = 0; }
             pdl_sync();
         }
         const uint32_t bn = (uint32_t) __builtin_amdgcn_readfirstlane((int) s_bn);
@@ -189,7 +197,10 @@ __global__ __launch_bounds__(PT_T, PT_WG_PER_CU) void k_join_part(JoinArgs a) {
 #pragma unroll
         for (uint32_t s = 1; s < PT_ROWS; s++) {
             lbv[s] = woff[PT_NW];
-            if (s < ns) { const uint2 v = s_lb[s]; const uint32_t vx = uni(v.x); lbv[s] = (vx == 0 ? woff[0] : vx == 1 ? woff[1] : vx == 2 ? woff[2] : woff[3]) + uni(v.y); }
+            if (s < ns) { const uint2 v = s_lb[s]; const uint32_t vx = uni(v.x); uint32_t wo = 0;
+#pragma unroll
+                for (uint32_t w = 0; w < PT_NW; w++) wo = vx == w ? woff[w] : wo;
+                lbv[s] = wo + uni(v.y); }
         }
         lbv[PT_ROWS] = woff[PT_NW];
         uint32_t ns_keep = 0;
@@ -242,7 +253,9 @@ __global__ __launch_bounds__(PT_T, PT_WG_PER_CU) void k_join_part(JoinArgs a) {
         const uint32_t cpw = (chunks + PT_NW - 1) / PT_NW;   // <= PT_KPT
         const uint32_t seg = cpw * PDL_WAVE;
         {
-            uint32_t ex = inc - sum + (wave == 0 ? woff[0] : wave == 1 ? woff[1] : wave == 2 ? woff[2] : woff[3]);
+            uint32_t ex = inc - sum;
+#pragma unroll
+            for (uint32_t w = 0; w < PT_NW; w++) ex += wave == w ? woff[w] : 0u;
 #pragma unroll
             for (uint32_t q = 0; q < PT_RPT; q++) {
                 const uint32_t i = tid * PT_RPT + q;

@@ -71,6 +71,7 @@ struct JoinArgs {
     uint32_t *overflow_count;
     uint32_t *error_count;         // internal consistency violations (must stay 0)
     uint32_t *overflow_rows;
+    uint4 *overflow_desc;          // (LDS tiers) the handed-on rows' descriptors, written beside their task positions: the next tier starts without a pass that makes them
 #ifdef PDL_JOIN_PHASES
     unsigned long long *phase;     // diagnostic build (-DPDL_JOIN_PHASES): time the first thread of every workgroup spends in the phases of a row (100-MHz ticks, summed)
 #endif
@@ -662,7 +663,7 @@ __global__ __launch_bounds__(T_, (FILTER && HT_BITS_ <= 10) ? 5 : (FILTER && T_ 
         const uint32_t ntouched = min(s_ntouched, TOUCH_CAP);
         if (s_overflow) {
             // too many keys for this table: hand the row to the next tier, wipe the table
-            if (tid == 0) a.overflow_rows[atomicAdd(a.overflow_count, 1u)] = p;
+            if (tid == 0) { const uint32_t oi = atomicAdd(a.overflow_count, 1u); a.overflow_rows[oi] = p; if (a.overflow_desc) a.overflow_desc[oi] = d; }
             pdl_sync();
             for (uint32_t i = tid; i < HT; i += T) { s_kf[i] = make_uint2(EMPTY_KEY, 0u); s_acc[i] = 0; }
             if (tid == 0) { s_ntouched = 0; s_nemit = 0; s_overflow = 0; s_next = next_reg; s_desc = next_desc; }
@@ -1305,18 +1306,6 @@ __global__ __launch_bounds__(256) void k_row_desc(const uint32_t *__restrict__ t
     desc[p] = make_uint4(p, r, e0, seq_off[r + 1] - e0);
 }
 
-// descriptors of the rows a tier handed on (list of task positions, length on the device)
-__global__ __launch_bounds__(256) void k_row_desc_list(const uint32_t *__restrict__ list, const uint32_t *__restrict__ n_list,
-                                                       const uint32_t *__restrict__ task_rows, const uint32_t *__restrict__ seq_off,
-                                                       uint4 *__restrict__ desc) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= *n_list) return;
-    const uint32_t p = list[i];
-    const uint32_t r = task_rows[p];
-    const uint32_t e0 = seq_off[r];
-    desc[i] = make_uint4(p, r, e0, seq_off[r + 1] - e0);
-}
-
 struct RowCntFlag {
     const uint32_t *row_cnt; const uint32_t *mirror_cnt;     // cells of a row = its own + the mirrored ones
     __device__ uint32_t operator()(uint64_t p) const { return row_cnt[p] + (mirror_cnt ? mirror_cnt[p] : 0u); }
@@ -1594,21 +1583,19 @@ static void score_join(pdl_ctx *c, const ScorePlan &pl) {
     a.work = nullptr; a.desc = c->row_desc.as<uint4>(); a.n_work = pl.wide ? 0 : n_rows; a.n_work_ptr = nullptr;
     if (pl.tier0) {
         a.work_cursor = ctr32 + 11; a.overflow_count = ctr32 + 12; a.overflow_rows = list_s; a.work_batch = PT_BATCH;
+        a.overflow_desc = c->row_desc2.as<uint4>() + n_rows;
         hipLaunchKernelGGL((k_join_part<PT_T, PT_WG_PER_CU>), dim3(pl.grid0), dim3(PT_T), 0, st, a);
         // ... its second form (512 threads: twice the lookups per cycle) over the rows that alone exceed the first form's cycle,
-        // one row per draw; what that cannot hold either is listed for tier 1
-        hipLaunchKernelGGL(k_row_desc_list, dim3((n_rows + 255) / 256), dim3(256), 0, st, list_s, ctr32 + 12, c->task_rows.as<uint32_t>(),
-                           c->seq_off.as<uint32_t>(), c->row_desc2.as<uint4>() + n_rows);
+        // one row per draw; what that cannot hold either is listed for tier 1 (a tier writes the descriptors of the rows it hands on)
         a.desc = c->row_desc2.as<uint4>() + n_rows; a.n_work = 0; a.n_work_ptr = ctr32 + 12;
         a.work_cursor = ctr32 + 13; a.overflow_count = ctr32 + 14; a.overflow_rows = list_s2; a.work_batch = 1;
+        a.overflow_desc = c->row_desc2.as<uint4>() + 2 * (size_t) n_rows;
         hipLaunchKernelGGL((k_join_part<PT_T2, PT_WGS2>), dim3(pl.grid0b), dim3(PT_T2), 0, st, a);
-        hipLaunchKernelGGL(k_row_desc_list, dim3((n_rows + 255) / 256), dim3(256), 0, st, list_s2, ctr32 + 14, c->task_rows.as<uint32_t>(),
-                           c->seq_off.as<uint32_t>(), c->row_desc2.as<uint4>() + 2 * (size_t) n_rows);
         a.desc = c->row_desc2.as<uint4>() + 2 * (size_t) n_rows; a.n_work = 0; a.n_work_ptr = ctr32 + 14;
         c->tm.join_launches += 2;
     }
     // tier 1
-    a.work_cursor = ctr32 + 0; a.overflow_count = ctr32 + 1; a.overflow_rows = list_a;
+    a.work_cursor = ctr32 + 0; a.overflow_count = ctr32 + 1; a.overflow_rows = list_a; a.overflow_desc = tier1 ? c->row_desc2.as<uint4>() : nullptr;
     a.work_batch = pl.tier0 ? 1 : std::max<uint32_t>(1, std::min<uint32_t>(8, n_rows / (std::max<uint32_t>(pl.grid1, 1) * 8)));      // (behind tier 0: few, long rows)
     if (tier1 >= 9 && tier1 <= 11) {
         // the filter tiers put a row's first sightings aside in a list per workgroup (16 bytes each; rewritten row after row, so
@@ -1646,12 +1633,8 @@ static void score_join(pdl_ctx *c, const ScorePlan &pl) {
     }
 #endif
     // tier 2 over list A (or over everything when tier 1 is off)
-    if (tier1) {
-        hipLaunchKernelGGL(k_row_desc_list, dim3((n_rows + 255) / 256), dim3(256), 0, st, list_a, ctr32 + 1, c->task_rows.as<uint32_t>(),
-                           c->seq_off.as<uint32_t>(), c->row_desc2.as<uint4>());
-        a.desc = c->row_desc2.as<uint4>(); a.n_work = 0; a.n_work_ptr = ctr32 + 1;
-    }
-    a.work_cursor = ctr32 + 2; a.overflow_count = ctr32 + 3; a.overflow_rows = list_b;
+    if (tier1) { a.desc = c->row_desc2.as<uint4>(); a.n_work = 0; a.n_work_ptr = ctr32 + 1; }
+    a.work_cursor = ctr32 + 2; a.overflow_count = ctr32 + 3; a.overflow_rows = list_b; a.overflow_desc = nullptr;      // (tier 3 goes by the task positions)
     a.work_batch = tier1 ? 1 : std::max<uint32_t>(1, std::min<uint32_t>(8, n_rows / (pl.grid2 * 8)));
     if (pl.wide && !tier1) a.n_work = 0;
     if (pl.tiny_tier2) hipLaunchKernelGGL((k_join_lds<9, 64, false>), dim3(pl.grid2), dim3(64), 0, st, a);

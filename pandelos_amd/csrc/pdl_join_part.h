@@ -129,7 +129,7 @@ __global__ __launch_bounds__(TT, WGS) void k_join_part(JoinArgs a) {
             const uint4 d = s_bdesc[j];
             const uint32_t dw = uni(d.w), kc = uni(s_binfo[j].x);
             if (dw == 0) { if (tid == 0) { a.row_base[d.x] = 0; a.row_cnt[d.x] = 0; } continue; }
-            if (dw > PT_RB || kc <= two_k) { if (tid == 0) a.overflow_rows[atomicAdd(a.overflow_count, 1u)] = d.x; continue; }
+            if (dw > PT_RB || kc <= two_k) { if (tid == 0) { const uint32_t oi = atomicAdd(a.overflow_count, 1u); a.overflow_rows[oi] = d.x; a.overflow_desc[oi] = d; } continue; }
             break;
         }
         if (j >= bn) { pdl_sync(); if (tid == 0) s_bpos = j; continue; }        // (uniform)
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(TT, WGS) void k_join_part(JoinArgs a) {
         ns_keep = (uint32_t) __builtin_amdgcn_readfirstlane((int) ns_keep);
         if (ns_keep == 0) {                                  // (uniform) the head row alone has more lookups than a cycle takes
             pdl_sync();
-            if (tid == 0) { a.overflow_rows[atomicAdd(a.overflow_count, 1u)] = s_bdesc[jv[0]].x; s_bpos = jv[0] + 1; }
+            if (tid == 0) { const uint4 d = s_bdesc[jv[0]]; const uint32_t oi = atomicAdd(a.overflow_count, 1u); a.overflow_rows[oi] = d.x; a.overflow_desc[oi] = d; s_bpos = jv[0] + 1; }
             continue;
         }
         const uint32_t total = (uint32_t) __builtin_amdgcn_readfirstlane((int) (ns_keep == 1 ? lbv[1] : ns_keep == 2 ? lbv[2] : ns_keep == 3 ? lbv[3] : lbv[4]));
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(TT, WGS) void k_join_part(JoinArgs a) {
             pdl_sync();
             for (uint32_t i = tid; i < PT_HT; i += PT_T) { s_tkey[i] = 0; s_tn[i] = 0; }
             const bool hand_on = ns_keep == 1;
-            if (tid == 0 && hand_on) a.overflow_rows[atomicAdd(a.overflow_count, 1u)] = s_row[0].p;
+            if (tid == 0 && hand_on) { const uint4 d = s_bdesc[jv[0]]; const uint32_t oi = atomicAdd(a.overflow_count, 1u); a.overflow_rows[oi] = d.x; a.overflow_desc[oi] = d; }
             if (tid < PT_ROWS) s_tslot[tid] = 0;
             if (tid == 0) {
                 s_nheavy = 0; s_ntouched = 0; s_overflow = 0;

@@ -27,8 +27,12 @@
 //   finalize  touched slots only, exactly as in the other tiers.
 //
 // h is a bijection of the 22-bit gene id (odd multiplier mod 2^22), so the column comes back out of the key.  LDS 31 KB:
-// five workgroups per CU.  Rows this tier does not take (more than 960 ranges or 4 096 lookups on their own, a gene of
-// <= 2k k-mers, too many columns or heavy lookups) go to the filter tier through the usual device-side list.
+// five workgroups per CU.  The kernel is a template of its thread count and is launched twice: 256 threads (a cycle of 4 096
+// lookups) over every row, then 512 threads (8 192 lookups, one row per draw) over the rows that alone exceed the first form's
+// cycle — on the 64-genome set 923 rows of 4 100-7 200 lookups, which as rows of the filter tier (one per workgroup) made that
+// launch last as long as its longest row.  Rows neither form takes (more than 960 ranges or 8 192 lookups, a gene of <= 2k
+// k-mers, too many columns or heavy lookups) go to the filter tier through the usual device-side list; a tier writes the
+// descriptors of the rows it hands on, so the next one starts without a pass that makes them.
 #pragma once
 
 constexpr uint32_t PT_T = 256;                           // threads of the kernel's first form (the second, for the rows that exceed its cycle, has PT_T2)

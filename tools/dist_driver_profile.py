@@ -1,5 +1,10 @@
+#!/usr/bin/env python3
+"""Where the wall time of one multi-GPU step goes on the host side: the torch.distributed driver (pandelos_amd/distributed.py)
+under RCCL with a group of ONE on cuda:0 — every collective is issued, nothing travels — with the library calls, the small
+all-gathers, the all-to-alls, the allocations and the views of library memory timed one by one (each bracketed by a device
+synchronisation, so the sum is more than the step).   usage: python tools/dist_driver_profile.py"""
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["MASTER_ADDR"]="127.0.0.1"; os.environ["MASTER_PORT"]="29533"
 import numpy as np, torch, torch.distributed as dist
 torch.cuda.set_device(0)

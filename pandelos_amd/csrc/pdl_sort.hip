@@ -71,7 +71,8 @@ struct RsOffsApply {
 template <class KeyT, class ValT>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const KeyT *__restrict__ keys_in, const ValT *vals_in,
                                                            KeyT *__restrict__ keys_out, ValT *__restrict__ vals_out, uint64_t n_bound,
-                                                           const uint64_t *d_n, uint32_t shift, uint32_t n_tiles, const uint32_t *__restrict__ offs) {
+                                                           const uint64_t *d_n, uint32_t shift, uint32_t n_tiles, const uint32_t *__restrict__ offs,
+                                                           uint32_t nbits) {       // significant bits of this pass's digit (the last pass of a sort may have fewer than 8)
     const uint64_t n = scan_count(n_bound, d_n);
     if ((uint64_t) blockIdx.x * (RS_THREADS * RS_ROUNDS) >= n) return;       // (uniform) tile past the end
     __shared__ KeyT s_key[RS_TILE];
@@ -91,7 +92,6 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const KeyT *__restric
     KeyT key[RS_ROUNDS];
     ValT val[RS_ROUNDS];
     uint16_t rank[RS_ROUNDS];          // position among the wave's elements of the same digit
-    const unsigned long long below = (1ull << lane) - 1ull;
     // every load of the tile first, branch-free (clamped index): thirty-two loads in flight per lane.  Behind a branch or
     // an LDS store the compiler keeps program order and would wait for each round's load before ranking it.
 #pragma unroll
@@ -117,13 +117,15 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const KeyT *__restric
         unsigned long long same = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < 8; b++) {
+            if ((uint32_t) b >= nbits) break;                       // (uniform) the bits above are zero in every key
             const unsigned long long m = __ballot((d >> b) & 1u);
             same &= ((d >> b) & 1u) ? m : ~m;
         }
         // `same` = valid lanes of this wave holding digit d in this round
         const uint32_t before = s_cnt[wave][d];                     // earlier rounds (own wave only: no race)
-        rank[j] = (uint16_t) (before + (uint32_t) __popcll(same & below));
-        if (valid && (same & below) == 0) s_cnt[wave][d] = before + (uint32_t) __popcll(same);   // lowest lane of the set
+        const uint32_t below_me = __builtin_amdgcn_mbcnt_hi((uint32_t) (same >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) same, 0u));     // lanes of the set below this one
+        rank[j] = (uint16_t) (before + below_me);
+        if (valid && below_me == 0) s_cnt[wave][d] = before + (uint32_t) __popcll(same);   // lowest lane of the set
     }
     pdl_sync();
     // tile-level layout: digit runs in digit order, inside a run wave 0's elements first
@@ -179,7 +181,8 @@ void pdl_sort_pairs(pdl_ctx *c, KeyT *&keys_in, KeyT *&keys_out, ValT *&vals_in,
         hipLaunchKernelGGL((k_rs_hist<KeyT>), dim3(n_tiles), dim3(RS_THREADS), 0, c->stream, keys_in, n, d_n, shift, n_tiles, counts);
         scan_and_apply(c, table, RsCountFlag{counts}, RsOffsApply{offs}, d_total);
         hipLaunchKernelGGL((k_rs_scatter<KeyT, ValT>), dim3(n_tiles), dim3(RS_THREADS), 0, c->stream, keys_in,
-                           (p == begin_bit / 8 && iota_values) ? (const ValT *) nullptr : vals_in, keys_out, vals_out, n, d_n, shift, n_tiles, offs);
+                           (p == begin_bit / 8 && iota_values) ? (const ValT *) nullptr : vals_in, keys_out, vals_out, n, d_n, shift, n_tiles, offs,
+                           std::min<uint32_t>(8, end_bit - shift));
         PDL_HIP(hipGetLastError());
         std::swap(keys_in, keys_out);
         std::swap(vals_in, vals_out);

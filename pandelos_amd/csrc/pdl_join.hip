@@ -1584,7 +1584,26 @@ static void score_join(pdl_ctx *c, const ScorePlan &pl) {
     if (pl.tier0) {
         a.work_cursor = ctr32 + 11; a.overflow_count = ctr32 + 12; a.overflow_rows = list_s; a.work_batch = PT_BATCH;
         a.overflow_desc = c->row_desc2.as<uint4>() + n_rows;
+#ifdef PDL_JOIN_PHASES
+        static unsigned long long *d_phase0 = nullptr;
+        if (!d_phase0) PDL_HIP(hipMalloc((void **) &d_phase0, 12 * sizeof(unsigned long long)));
+        PDL_HIP(hipMemsetAsync(d_phase0, 0, 12 * sizeof(unsigned long long), st));
+        a.phase = d_phase0;
+#endif
         hipLaunchKernelGGL((k_join_part<PT_T, PT_WG_PER_CU>), dim3(pl.grid0), dim3(PT_T), 0, st, a);
+#ifdef PDL_JOIN_PHASES
+        {   // (the first form only; the timers are thread 0's clock between the barriers: shares of a workgroup's time, other workgroups of the CU run beside it)
+            unsigned long long h[12];
+            PDL_HIP(hipMemcpyAsync(h, d_phase0, sizeof(h), hipMemcpyDeviceToHost, st));
+            PDL_HIP(hipStreamSynchronize(st));
+            const double per = 10.0 / 1000.0 / std::max<uint32_t>(pl.grid0, 1);       // ticks of 10 ns -> us per workgroup
+            fprintf(stderr, "tier 0 phases per workgroup (us): draw + pick %.1f  stage %.1f  prefixes %.1f  walk %.1f  sift + add %.1f  finalize %.1f  | rows/wg %.1f\n",
+                    h[0] * per, h[1] * per, h[2] * per, h[3] * per, h[4] * per, h[5] * per, (double) n_rows / std::max<uint32_t>(pl.grid0, 1));
+            fprintf(stderr, "tier 0 counts: cycles %llu (%.2f rows, %.0f lookups each)  cycles that overflowed %llu  survivors of wave 0 %llu (x4 = %.1f %% of the lookups)  probe steps of thread 0: %llu\n",
+                    h[6], (double) h[11] / std::max<unsigned long long>(h[6], 1), (double) h[10] / std::max<unsigned long long>(h[6], 1), h[7], h[8], 400.0 * h[8] / std::max<unsigned long long>(h[10], 1), h[9]);
+            a.phase = nullptr;
+        }
+#endif
         // ... its second form (512 threads: twice the lookups per cycle) over the rows that alone exceed the first form's cycle,
         // one row per draw; what that cannot hold either is listed for tier 1 (a tier writes the descriptors of the rows it hands on)
         a.desc = c->row_desc2.as<uint4>() + n_rows; a.n_work = 0; a.n_work_ptr = ctr32 + 12;

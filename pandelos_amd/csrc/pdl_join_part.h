@@ -107,9 +107,19 @@ __global__ __launch_bounds__(TT, WGS) void k_join_part(JoinArgs a) {
     const uint32_t tc_min = min_numerator(threshold, (float) (int) a.min_kseq);
     const bool track_first = a.canonical == 0;
     const uint32_t two_k = 2 * a.k;
+#ifdef PDL_JOIN_PHASES
+    // diagnostic build: where a workgroup's time goes, by the clock of its first thread (100-MHz ticks): 0 draw + pick the cycle's
+    // rows | 1 stage | 2 prefixes, segment starts | 3 walk | 4 sift + add | 5 staging room, finalize, emit; and what it worked on
+    unsigned long long pph[6] = {0, 0, 0, 0, 0, 0}, pt_prev = wall_clock64();
+    unsigned long long pt_cycles = 0, pt_over = 0, pt_surv = 0, pt_probe = 0, pt_look = 0, pt_rows = 0;       // (thread 0 / wave 0 count; survivors of wave 0, probe steps of thread 0 only)
+#define PT_MARK(i) do { if (tid == 0) { const unsigned long long t_now = wall_clock64(); pph[i] += t_now - pt_prev; pt_prev = t_now; } } while (0)
+#else
+#define PT_MARK(i) do { } while (0)
+#endif
 
     for (;;) {
         pdl_sync();
+        PT_MARK(5);
         // ---- rows: a batch of consecutive work items at a time -------------------------------------------------------
         if (s_bpos >= s_bn) {                                // (uniform) batch used up: draw the next one
             if (tid == 0) s_w0 = atomicAdd(a.work_cursor, batch);
@@ -137,6 +147,7 @@ __global__ __launch_bounds__(TT, WGS) void k_join_part(JoinArgs a) {
             break;
         }
         if (j >= bn) { pdl_sync(); if (tid == 0) s_bpos = j; continue; }        // (uniform)
+        PT_MARK(0);
         // the cycle's rows: consecutive ordinary rows while their ranges fit
         const bool solo = uni(s_solo) != 0;                  // after a cycle whose rows did not fit the table together: one row at a time
         uint32_t ns = 0, nb = 0, rbv[PT_ROWS + 1], e0v[PT_ROWS], jv[PT_ROWS];
@@ -191,6 +202,7 @@ __global__ __launch_bounds__(TT, WGS) void k_join_part(JoinArgs a) {
             }
         }
         pdl_sync();
+        PT_MARK(1);
         uint32_t woff[PT_NW + 1];
         woff[0] = 0;
 #pragma unroll
@@ -232,6 +244,9 @@ __global__ __launch_bounds__(TT, WGS) void k_join_part(JoinArgs a) {
             uint32_t ts = hk >> (22 - sub_bits);
             bool placed = false;
             for (uint32_t step = 0; step <= sub_mask; step++) {          // (bounded: a full part of the table ends the search)
+#ifdef PDL_JOIN_PHASES
+                if (tid == 0) pt_probe++;
+#endif
                 const uint32_t w = s_tkey[tbase + ts];
                 if (w != 0u && ((w - 1u) >> 10) == hk) { placed = true; break; }             // this column of this row sits here
                 if (w == 0u) {
@@ -280,6 +295,7 @@ __global__ __launch_bounds__(TT, WGS) void k_join_part(JoinArgs a) {
             }
         }
         pdl_sync();
+        PT_MARK(2);
         // ---- walk: one key per lookup, kept in a register; the column marked "seen" / "seen twice" ----------------------------
         // (lane -> range mapping as in k_join_lds: one coalesced read of the next 64 range starts per step, boundaries by
         // ds_permute + ballot + popcount)
@@ -374,6 +390,7 @@ __global__ __launch_bounds__(TT, WGS) void k_join_part(JoinArgs a) {
             }
         }
         pdl_sync();
+        PT_MARK(3);
         // ---- sift + add ------------------------------------------------------------------------------------------------------------------
         // sift: the lookups that are not alone on their bit are compacted into the wave's list (bm1 and the prefix array are done
         // with); add: the list goes to the table, two keys per lane at a time
@@ -408,11 +425,18 @@ __global__ __launch_bounds__(TT, WGS) void k_join_part(JoinArgs a) {
                     const unsigned long long mk = __ballot(keep);
                     if (keep) wlist[nsv + (uint32_t) __popcll(mk & ((1ull << lane) - 1ull))] = key[i];
                     nsv += (uint32_t) __popcll(mk);
+#ifdef PDL_JOIN_PHASES
+                    if (tid == 0) pt_surv += (uint32_t) __popcll(mk);
+#endif
                 }
             }
             drain();
         }
         pdl_sync();
+        PT_MARK(4);
+#ifdef PDL_JOIN_PHASES
+        if (tid == 0) { pt_cycles++; pt_look += total; pt_rows += ns_keep; if (uni(s_overflow)) pt_over++; }
+#endif
         if (uni(s_overflow)) {     // (uniform, rare) a row's part of the table is full: the table is wiped; several rows are tried again one by one, a single one goes to the filter tier
             pdl_sync();
             for (uint32_t i = tid; i < PT_HT; i += PT_T) { s_tkey[i] = 0; s_tn[i] = 0; }
@@ -505,4 +529,12 @@ __global__ __launch_bounds__(TT, WGS) void k_join_part(JoinArgs a) {
         pdl_sync();
         if (tid < PT_ROWS) { s_tslot[tid] = 0; s_nemit[tid] = 0; }
     }
+#ifdef PDL_JOIN_PHASES
+    if (tid == 0 && a.phase) {
+        for (int i = 0; i < 6; i++) atomicAdd(&a.phase[i], pph[i]);
+        atomicAdd(&a.phase[6], pt_cycles); atomicAdd(&a.phase[7], pt_over); atomicAdd(&a.phase[8], pt_surv); atomicAdd(&a.phase[9], pt_probe);
+        atomicAdd(&a.phase[10], pt_look); atomicAdd(&a.phase[11], pt_rows);
+    }
+#endif
+#undef PT_MARK
 }

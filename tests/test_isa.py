@@ -127,3 +127,15 @@ def test_negative_control_a_bare_syncthreads_is_flagged(tmp_path):
     bad, n = barrier_violations(_disassemble_code_object(co))
     assert n > 50
     assert any("k_join_lds" in fn for fn, _, _ in bad), "the compiler emitted an LDS wait in front of every barrier by itself: the control no longer bites"
+
+
+@pytest.mark.skipif(not HIPCC.exists(), reason="no hipcc")
+def test_diagnostic_builds_compile_and_keep_the_barrier_rule(tmp_path):
+    """-DPDL_JOIN_PHASES (phase timers and counts inside the join tiers) and -DPDL_JOIN_CHECK (lane -> range mapping checked
+    against the prefix array, wave lag) are how the findings of DESIGN.md section 4 were made: they must keep compiling for
+    gfx950, and the barrier rule holds for them too."""
+    co = tmp_path / "join_diag.co"
+    subprocess.run([str(HIPCC), "--offload-arch=gfx950", "-O3", "-std=c++17", "-DPDL_JOIN_PHASES", "-DPDL_JOIN_CHECK", "--cuda-device-only",
+                    "--no-gpu-bundle-output", "-c", str(ROOT / "pandelos_amd" / "csrc" / "pdl_join.hip"), "-o", str(co)], check=True)
+    bad, n = barrier_violations(_disassemble_code_object(co))
+    assert n > 50 and not bad, bad[:5]

@@ -340,7 +340,7 @@ template <class KeyT> struct SelFlag {
 template <class KeyT> struct SelApply {
     const KeyT *keys; const uint32_t *vals; KeyT *keys_out; uint32_t *vals_out;
     struct Loaded { KeyT key; uint32_t val; };
-    __device__ Loaded load(uint64_t q, uint32_t) const { return Loaded{keys[q], vals[q]}; }
+    __device__ Loaded load(uint64_t q, uint32_t f) const { return f ? Loaded{keys[q], vals[q]} : Loaded{0, 0u}; }      // (seven k-mers in eight belong to other ranks: their key and gene are not read again)
     __device__ void store(uint64_t, uint32_t f, uint32_t prefix, const Loaded &v) const { if (f) { keys_out[prefix] = v.key; vals_out[prefix] = v.val; } }
 };
 

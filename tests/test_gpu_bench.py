@@ -39,11 +39,13 @@ def test_default_run_prints_the_contract_line():
     assert d["pipeline"]["faa_to_net_ms"] > d["pipeline"]["dictionary_ms"] > 0
 
 
-def test_two_ranks_rehearsed_on_one_device_print_the_contract_line():
+def test_two_ranks_print_the_contract_line():
     d = _bench("--gpus", "2", "--steps", "3", "--warmup", "1")
     for k in CONTRACT:
         assert k in d, k
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d.get("rehearsal") is True
+    import torch
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert bool(d.get("rehearsal", False)) == (torch.cuda.device_count() < 2)        # (a box with two GPUs runs the two ranks over RCCL for real)
     st = d["stage_ms"]
     assert st["range_lists_by"] == "senders" and st["dist_ranges"] > 0 and st["dist_finish"] > 0 and st["aside_reloads"] == 0
     assert d["scale_set"]["n_gpus"] == 2 and d["scale_set"]["emitted_cells"] == 55236320       # (configs[3]: the reference's count, summed over the ranks)

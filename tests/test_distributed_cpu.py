@@ -81,8 +81,8 @@ class _FakeRank:
         self.run_weights = np.arange(genomes, dtype=np.int64) * (rank + 1)
         self.run_costs = np.arange(genomes, dtype=np.int64) * (rank + 3) + 1
         self.cost = "cost"
-        # range tuples for rank d: (rank + 2) * (d + 1) of them (also for myself: a rank owns genes of its own run too)
-        self.tcounts = np.array([(rank + 2) * (d + 1) for d in range(world)], dtype=np.int64)
+        # range tuples for rank d: (rank + 2) * (d + 1) of them (also for myself: a rank owns genes of its own run too), or none
+        self.tcounts = np.array([0 if (rank + d) % 3 == 0 else (rank + 2) * (d + 1) for d in range(world)], dtype=np.int64)     # (some pairs exchange nothing, rank 0 keeps nothing for itself)
         self.tkeys = torch.tensor([(d << 24) | (rank << 8) | i for d in range(world) for i in range(int(self.tcounts[d]))], dtype=torch.int32)
         self.tranges = torch.tensor([(rank << 40) | (d << 20) | i for d in range(world) for i in range(int(self.tcounts[d]))], dtype=torch.int64)
         self.tctr = np.array([10 + rank, 20 + rank, 30 + rank], dtype=np.int64)

@@ -1,9 +1,11 @@
 #!/bin/bash
-# The host side of the .faa ingest (pdl_ingest.hip: chunks at line starts, a team of threads, three passes) under the sanitizers
-# of the ROCm clang, on the CPU build only (the GPU pool takes no sanitizer runs):
+# Host code under the sanitizers, on the CPU build only (the GPU pool takes no sanitizer runs).  The .faa ingest (pdl_ingest.hip:
+# chunks at line starts, a team of threads, three passes) under those of the ROCm clang:
 #   1. AddressSanitizer + UBSan: libpandelos_amd.so with an instrumented pdl_ingest.o, the CPU tests of tests/test_ingest.py
 #   2. ThreadSanitizer: a small driver calling pdl_scan_faa (count pass + fill pass) on two messy 3-MB files, six times
-# usage: bash tools/sanitize_ingest.sh        (needs a built pandelos_amd/lib/obj; leaves the shipped library as it was)
+#   3. the native host's network container + .net text (pangenes_main.cpp, struct Net: counting sorts, eight formatting threads) cut
+#      out of its source into a harness with 479 k synthetic edges: g++ ASan + UBSan, then ThreadSanitizer
+# usage: bash tools/sanitize_host.sh        (needs a built pandelos_amd/lib/obj; leaves the shipped library as it was)
 set -e
 cd "$(dirname "$0")/.."
 W=/tmp/pdl_sanitize; rm -rf $W; mkdir -p $W
@@ -43,4 +45,36 @@ CPP
 /opt/rocm/lib/llvm/bin/clang++ -O1 -g -std=c++17 -fsanitize=thread -Iinclude -c $W/drv.cpp -o $W/drv.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -fsanitize=thread $W/drv.o $W/ing_tsan.o $OBJS -o $W/drv_tsan -lpthread 2>/dev/null
 TSAN_OPTIONS=halt_on_error=1 $W/drv_tsan $W/messy1.faa $W/messy2.faa
+python3 - <<'PY'
+src = open("pandelos_amd/csrc/pangenes_main.cpp").read()
+body = src[src.index("namespace {"):src.index("void usage()")]
+open("/tmp/pdl_sanitize/net.cpp", "w").write("""#include <algorithm>
+#include <charconv>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <random>
+#include <string>
+#include <thread>
+#include <vector>
+""" + body + """}
+int main() {
+    const int N = 47891; std::mt19937 rng(7);
+    Net net;
+    for (int g = 0; g < N; g++) for (int j = 0; j < 5; j++) {
+        const int o = (g + (int) (rng() % 64 + 1) * 750) % N; const float sc = (rng() % 100000) / 100000.0f * 0.9f + 0.05f;
+        net.add(g, o, sc); net.add(o, g, sc);
+    }
+    size_t bytes = 0;
+    for (int rep = 0; rep < 3; rep++) { bytes = 0; for (const std::string &p : net.text()) bytes += p.size(); }
+    printf("net text: %zu bytes\\n", bytes);
+    return 0;
+}
+""")
+PY
+g++ -O1 -g -std=c++17 -pthread -fsanitize=address,undefined -fno-sanitize-recover=all $W/net.cpp -o $W/net_asan && $W/net_asan
+g++ -O1 -g -std=c++17 -pthread -fsanitize=thread $W/net.cpp -o $W/net_tsan && TSAN_OPTIONS=halt_on_error=1 $W/net_tsan
 echo "sanitizers: no report"

@@ -106,8 +106,10 @@ struct RankParams {
     uint64_t last_multiplier;
     uint32_t base;          // B (kept as the reference's unsigned char value)
     uint32_t k;
-    uint32_t rank_bits;
+    uint32_t rank_bits;     // bits of a rank as rank_init sees them: what the sort by rank goes over (the reference's rank_byte_order bytes)
     uint32_t hash_fallback;
+    uint32_t key_bits;      // bits a rank can really occupy: rank_bits — or 64 where B^k wrapped past 2^64 UNNOTICED by rank_init's overflow test
+                            // (library.cpp:104-111 looks one multiplication ahead with wrapped products: 22 letters, k = 15), the ranks being the polynomial mod 2^64
 };
 
 struct EventPair {

@@ -89,12 +89,18 @@ static void rank_init_host(RankParams &rp, const uint64_t counters[256], int kva
     }
     rp.last_multiplier = last_multiplier;
     rp.hash_fallback = has_overflow ? 1u : 0u;
+    rp.key_bits = 64;
     if (has_overflow) {
         rp.rank_bits = 64;
     } else {
         uint64_t rank_tmp = last_multiplier * rank_base;   // B^k, fits (the loop above looked one step ahead)
         rp.rank_bits = rank_tmp ? bit_length64(rank_tmp - 1) : 1;
         if (rp.rank_bits == 0) rp.rank_bits = 1;
+        // did B^k fit?  (exact arithmetic: the reference's test compares wrapped products and lets some wraps through)
+        unsigned __int128 exact = 1;
+        bool fits = true;
+        for (int i = 0; i < kvalue && fits; i++) { exact *= rank_base; fits = (exact >> 64) == 0; }
+        if (fits) rp.key_bits = rp.rank_bits;
     }
 }
 
@@ -1192,7 +1198,7 @@ template <class KeyT>
 static void stage_sort_and_dedup(pdl_ctx *c, KeyT *keys_in, KeyT *keys_out, uint32_t *vals_in, uint32_t *vals_out, uint64_t m) {
     uint64_t *d_scal = c->scalars.as<uint64_t>();
     ev_begin(c, EV_SORT1);
-    pdl_sort_pairs<KeyT>(c, keys_in, keys_out, vals_in, vals_out, m, c->rp.rank_bits);
+    pdl_sort_pairs<KeyT>(c, keys_in, keys_out, vals_in, vals_out, m, c->rp.rank_bits, false, nullptr, 0, c->rp.key_bits == c->rp.rank_bits);
     ev_end(c, EV_SORT1);
     // remember which physical buffers hold the sorted stream (pdl_get_dictionary reads them)
     if ((void *) keys_out != c->keys_b.p) { std::swap(c->keys_a.p, c->keys_b.p); std::swap(c->keys_a.bytes, c->keys_b.bytes); }
@@ -1361,15 +1367,15 @@ static void stage_ranges_and_costs(pdl_ctx *c, uint64_t bound, int mode, bool on
         if (packed) {
             if (fused) {                     // pass 1 is done: (k2b, pay_b) hold its output, the remaining passes go on from there
                 std::swap(k2a, k2b); std::swap(pay_a, pay_b);
-                pdl_sort_pairs<uint32_t, unsigned long long>(c, k2a, k2b, pay_a, pay_b, n_sort, seq_bits, false, d_sort_n, 8);
+                pdl_sort_pairs<uint32_t, unsigned long long>(c, k2a, k2b, pay_a, pay_b, n_sort, seq_bits, false, d_sort_n, 8, true);
             } else
-            pdl_sort_pairs<uint32_t, unsigned long long>(c, k2a, k2b, pay_a, pay_b, n_sort, seq_bits, false, d_sort_n);   // sorted pairs now in (k2b, pay_b)
+            pdl_sort_pairs<uint32_t, unsigned long long>(c, k2a, k2b, pay_a, pay_b, n_sort, seq_bits, false, d_sort_n, 0, true);   // sorted pairs now in (k2b, pay_b)
             ev_end(c, EV_SORT2);
             ev_begin(c, EV_RANGES);
             c->ranges8 = reinterpret_cast<const uint2 *>(pay_b);       // gene major: the join reads them where the sort left them
             c->costs_ready = false;
         } else {
-            pdl_sort_pairs<uint32_t>(c, k2a, k2b, v2a, v2b, n_sort, seq_bits, true, d_sort_n);     // values = tuple positions; sorted pairs now in (k2b, v2b)
+            pdl_sort_pairs<uint32_t>(c, k2a, k2b, v2a, v2b, n_sort, seq_bits, true, d_sort_n, 0, true);     // values = tuple positions; sorted pairs now in (k2b, v2b)
             ev_end(c, EV_SORT2);
             ev_begin(c, EV_RANGES);
             c->ranges8 = nullptr;
@@ -1528,7 +1534,11 @@ static void dist_slice_pipeline(pdl_ctx *c) {
     const uint32_t W = c->world, me = c->rank;
     // 1. every k-mer's rank, and as a by-product the k-mers per bin of the rank space (top DIST_BIN_BITS bits of a rank)
     ev_begin(c, EV_RANK);
-    const uint32_t shift = c->rp.rank_bits > DIST_BIN_BITS ? c->rp.rank_bits - DIST_BIN_BITS : 0;
+    // (the bins go over the bits a rank can occupy; where ranks wrapped unnoticed AND the reference's sort goes over fewer bytes than
+    // they fill, its dictionary is ordered by the low bytes only: intervals of the high bits cannot reproduce that across GPUs)
+    if (c->rp.key_bits != c->rp.rank_bits && c->rp.rank_bits <= 56)
+        PDL_FAIL(PDL_ERR_UNSUPPORTED, "k-mer ranks wrap past 2^64 unnoticed by the reference's overflow test and its sort covers %u bits of them: one GPU reproduces that order, several do not", c->rp.rank_bits);
+    const uint32_t shift = c->rp.key_bits > DIST_BIN_BITS ? c->rp.key_bits - DIST_BIN_BITS : 0;
     c->scratch2.alloc(std::max<size_t>(c->scratch2.bytes, DIST_BINS * sizeof(uint32_t)));
     uint32_t *d_bins = c->scratch2.as<uint32_t>();
     PDL_HIP(hipMemsetAsync(d_bins, 0, DIST_BINS * sizeof(uint32_t), st));
@@ -1774,7 +1784,7 @@ bool pdl_run_dist_ranges(pdl_ctx *c, const uint64_t *run_records, const uint64_t
         launch_group_tiles<1, 1, false, false>(c, ga, grid);
         if (n_t) {
             hipLaunchKernelGGL(k_owner_keys, dim3((uint32_t) std::min<uint64_t>((n_t + 255) / 256, (uint64_t) c->cus * 16)), dim3(256), 0, st, k2a, d_scal + 2, c->seq_owner.as<uint8_t>());
-            pdl_sort_pairs<uint32_t, unsigned long long>(c, k2a, k2b, pay_a, pay_b, n_t, 32, false, nullptr, 24);      // -> (k2b, pay_b), by destination
+            pdl_sort_pairs<uint32_t, unsigned long long>(c, k2a, k2b, pay_a, pay_b, n_t, 32, false, nullptr, 24, true);      // -> (k2b, pay_b), by destination
             c->tuple_off.alloc(((size_t) W + 1) * sizeof(uint32_t));
             hipLaunchKernelGGL(k_seq_offsets, dim3((W + 1 + 255) / 256), dim3(256), 0, st, k2b, d_scal + 2, W, c->tuple_off.as<uint32_t>(), 24u, 0xffu);
             PDL_HIP(hipGetLastError());
@@ -1821,7 +1831,7 @@ void pdl_run_dist_finish_ranges(pdl_ctx *c, uint64_t total, uint32_t *d_keys, un
     unsigned long long *pay_a = d_ranges, *pay_b = c->scratch.as<unsigned long long>();
     uint32_t *k2a = d_keys, *k2b = reinterpret_cast<uint32_t *>(pay_b + cap);
     c->dist_out_keys = nullptr; c->dist_out_ranges = nullptr; c->dist_out_total = 0;
-    if (n_in) pdl_sort_pairs<uint32_t, unsigned long long>(c, k2a, k2b, pay_a, pay_b, n_in, seq_bits, false, nullptr);      // the gene bits only: the owner byte is the same everywhere
+    if (n_in) pdl_sort_pairs<uint32_t, unsigned long long>(c, k2a, k2b, pay_a, pay_b, n_in, seq_bits, false, nullptr, 0, true);      // the gene bits only (gene ids have 22 bits at most: the owner byte lies above every digit)
     else { k2b = k2a; pay_b = pay_a; }
     ev_end(c, EV_SORT2);
     ev_begin(c, EV_RANGES);

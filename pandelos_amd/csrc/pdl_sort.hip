@@ -165,7 +165,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const KeyT *__restric
 
 template <class KeyT, class ValT>
 void pdl_sort_pairs(pdl_ctx *c, KeyT *&keys_in, KeyT *&keys_out, ValT *&vals_in, ValT *&vals_out,
-                    uint64_t n, uint32_t end_bit, bool iota_values, const uint64_t *d_n, uint32_t begin_bit) {
+                    uint64_t n, uint32_t end_bit, bool iota_values, const uint64_t *d_n, uint32_t begin_bit, bool keys_below_end_bit) {
     if (n == 0) return;
     if (end_bit == 0) end_bit = 1;
     if (end_bit > sizeof(KeyT) * 8) end_bit = sizeof(KeyT) * 8;
@@ -182,7 +182,7 @@ void pdl_sort_pairs(pdl_ctx *c, KeyT *&keys_in, KeyT *&keys_out, ValT *&vals_in,
         scan_and_apply(c, table, RsCountFlag{counts}, RsOffsApply{offs}, d_total);
         hipLaunchKernelGGL((k_rs_scatter<KeyT, ValT>), dim3(n_tiles), dim3(RS_THREADS), 0, c->stream, keys_in,
                            (p == begin_bit / 8 && iota_values) ? (const ValT *) nullptr : vals_in, keys_out, vals_out, n, d_n, shift, n_tiles, offs,
-                           std::min<uint32_t>(8, end_bit - shift));
+                           keys_below_end_bit ? std::min<uint32_t>(8, end_bit - shift) : 8u);
         PDL_HIP(hipGetLastError());
         std::swap(keys_in, keys_out);
         std::swap(vals_in, vals_out);
@@ -198,6 +198,6 @@ void pdl_radix_offsets(pdl_ctx *c, const uint32_t *counts, uint32_t *offs, uint3
     scan_and_apply(c, (size_t) RS_BINS * n_tiles, RsCountFlag{counts}, RsOffsApply{offs}, d_total);
 }
 
-template void pdl_sort_pairs<uint32_t, uint32_t>(pdl_ctx *, uint32_t *&, uint32_t *&, uint32_t *&, uint32_t *&, uint64_t, uint32_t, bool, const uint64_t *, uint32_t);
-template void pdl_sort_pairs<uint64_t, uint32_t>(pdl_ctx *, uint64_t *&, uint64_t *&, uint32_t *&, uint32_t *&, uint64_t, uint32_t, bool, const uint64_t *, uint32_t);
-template void pdl_sort_pairs<uint32_t, unsigned long long>(pdl_ctx *, uint32_t *&, uint32_t *&, unsigned long long *&, unsigned long long *&, uint64_t, uint32_t, bool, const uint64_t *, uint32_t);
+template void pdl_sort_pairs<uint32_t, uint32_t>(pdl_ctx *, uint32_t *&, uint32_t *&, uint32_t *&, uint32_t *&, uint64_t, uint32_t, bool, const uint64_t *, uint32_t, bool);
+template void pdl_sort_pairs<uint64_t, uint32_t>(pdl_ctx *, uint64_t *&, uint64_t *&, uint32_t *&, uint32_t *&, uint64_t, uint32_t, bool, const uint64_t *, uint32_t, bool);
+template void pdl_sort_pairs<uint32_t, unsigned long long>(pdl_ctx *, uint32_t *&, uint32_t *&, unsigned long long *&, unsigned long long *&, uint64_t, uint32_t, bool, const uint64_t *, uint32_t, bool);

@@ -129,3 +129,26 @@ def pair_cells_digest(block, first_gene_a, first_gene_b, genome_b, excluded_a=()
     for f in ("scores", "percs", "tr_percs"):
         h.update(raw(np.asarray(block[f])[sel][keep][o]).astype("<u4").tobytes())
     return h.hexdigest(), int(len(r))
+
+
+def wrapped_rank_set(letters: int, seed: int, genomes: int = 4, per_genome: int = 12, length: int = 70):
+    """A small set over `letters` distinct ASCII letters — for k so large that B^k passes 2^64 while rank_init's overflow test
+    (library.cpp:104-111: wrapped products, one multiplication ahead) does not notice, e.g. 22 letters at k = 15, 24 at k = 14:
+    the ranks are then the polynomial mod 2^64 and fill all 64 bits although rank_init sees fewer.  -> pandelos_amd.synth.GeneSet"""
+    from pandelos_amd.synth import GeneSet
+    rng = np.random.default_rng(seed)
+    alpha = np.frombuffer(b"ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz", dtype=np.uint8)[:letters]
+    fams = [alpha[rng.integers(0, letters, int(rng.integers(length // 2, length * 2)))] for _ in range(per_genome)]
+    genes, gen, fam_of = [], [], []
+    for g in range(genomes):
+        for f, base in enumerate(fams):
+            if rng.random() < 0.15:
+                continue
+            s = base.copy()
+            m = rng.random(len(s)) < 0.05
+            s[m] = alpha[rng.integers(0, letters, int(m.sum()))]
+            genes.append(s); gen.append(g); fam_of.append(f)
+    genes[0][:letters] = alpha                       # every letter occurs
+    offsets = np.zeros(len(genes) + 1, np.uint64)
+    np.cumsum([len(x) for x in genes], out=offsets[1:])
+    return GeneSet(np.concatenate(genes).astype(np.uint8), offsets, np.asarray(gen, np.uint32), np.asarray(fam_of, np.int64))

@@ -493,3 +493,30 @@ def test_genome_batches_on_one_dictionary_reproduce_the_reference_digests(name, 
 def _lib_error():
     from pandelos_amd import _lib
     return _lib.PdlError
+
+
+@pytest.mark.parametrize("letters,k", [(22, 15), (24, 14), (11, 19), (20, 15)])
+def test_ranks_that_wrap_past_64_bits_unnoticed_match_the_oracle(letters, k):
+    """22 letters at k = 15 (24 at 14, 11 at 19): B^k passes 2^64, the reference's overflow test does not notice, and the ranks — the
+    polynomial mod 2^64 — fill all 64 bits while rank_init counts 63 (62).  The rank sort must still match whole digits (a pass
+    that matched only the bits rank_init counts put records where the histogram did not: a memory fault on seed 3078 of the wide
+    fuzz run); one GPU and three ranks against the oracle."""
+    from oracle import binding as ob
+    from pandelos_amd.distributed import LocalRanks
+    from tests.test_gpu_dist import _device_inputs
+    gs = H.wrapped_rank_set(letters, seed=letters * 100 + k)
+    ora = ob.Oracle(gs.residues, gs.offsets, gs.genome_of, k)
+    assert not ora.hash_fallback and ora.total_cost > 0
+    nat = _native(gs.residues, gs.offsets, gs.genome_of, k)
+    assert nat.cost.total_cost == ora.total_cost
+    want = [ora.scores(g) for g in range(ora.genomes)]
+    for g in range(ora.genomes):
+        H.assert_scores_equal(nat.generate_scores_part(g).as_dict(), want[g], f"{letters} letters k={k} genome {g}")
+    nat.close()
+    lr = LocalRanks(3)
+    lr.preprocess(k, *_device_inputs(gs.residues, gs.offsets, gs.genome_of), gs.genes, len(gs.residues))
+    assert lr.total_cost == ora.total_cost
+    lr.score_all()
+    for g in range(ora.genomes):
+        H.assert_scores_equal(lr.generate_scores_part(g).as_dict(), want[g], f"{letters} letters k={k} three ranks genome {g}")
+    lr.close()

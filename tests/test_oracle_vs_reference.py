@@ -31,6 +31,22 @@ def test_oracle_equals_reference_on_random_sets(tmp_path, shape, k):
         H.assert_scores_equal(o.scores(g), ref["per_genome"][g], f"genome {g}")
 
 
+@pytest.mark.parametrize("letters,k", [(22, 15), (24, 14), (11, 19)])
+def test_oracle_equals_reference_where_ranks_wrap_unnoticed(tmp_path, letters, k):
+    """B^k > 2^64 but rank_init's overflow test lets it through (it compares wrapped products): no hashing, the ranks are the
+    polynomial mod 2^64 and rank_byte_order comes from the wrapped B^k.  The oracle restates exactly that."""
+    gs = H.wrapped_rank_set(letters, seed=letters * 100 + k)
+    faa = tmp_path / "in.faa"
+    gs.write_faa(faa)
+    info = ob.run_harness(ob.REF_SO, faa, k, dump=tmp_path / "ref.bin")
+    ref = ob.read_dump(tmp_path / "ref.bin")
+    o = ob.Oracle(gs.residues, gs.offsets, gs.genome_of, k)
+    assert letters ** k >= 1 << 64 and not info["hash_fallback"] and not o.hash_fallback
+    assert o.total_cost == info["total_cost"] and info["total_cost"] > 0
+    for g in range(ref["genomes"]):
+        H.assert_scores_equal(o.scores(g), ref["per_genome"][g], f"genome {g}")
+
+
 def test_reference_is_thread_safe_in_harness(tmp_path):
     gs = make_gene_set(genomes=6, genes_per_genome=80, mean_len=50, sub_rate=0.05, seed=102)
     faa = tmp_path / "in.faa"

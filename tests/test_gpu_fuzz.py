@@ -48,7 +48,7 @@ def _random_set(seed):
     return residues.astype(np.uint8), offsets, np.asarray(gid, np.uint32), k
 
 
-@pytest.mark.parametrize("seed", list(range(3000, 3000 + int(os.environ.get("PDL_FUZZ_SEEDS", "60")))))   # widen with PDL_FUZZ_SEEDS=N
+@pytest.mark.parametrize("seed", list(range(3000, 3000 + int(os.environ.get("PDL_FUZZ_SEEDS", "240")))))   # widen with PDL_FUZZ_SEEDS=N
 def test_random_small_sets_match_the_oracle(seed):
     from oracle import binding as ob
     from pandelos_amd import _lib

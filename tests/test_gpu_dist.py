@@ -99,7 +99,7 @@ def test_canonical_order_and_tiny_staging_under_sharding():
     lr.close()
 
 
-@pytest.mark.parametrize("seed", list(range(5000, 5000 + int(os.environ.get("PDL_FUZZ_SEEDS_DIST", "60")))))   # widen with PDL_FUZZ_SEEDS_DIST=N
+@pytest.mark.parametrize("seed", list(range(5000 + int(os.environ.get("PDL_FUZZ_OFFSET", "0")), 5000 + int(os.environ.get("PDL_FUZZ_OFFSET", "0")) + int(os.environ.get("PDL_FUZZ_SEEDS_DIST", "60")))))   # widen with PDL_FUZZ_SEEDS_DIST=N
 def test_random_sets_sharded_match_the_oracle(seed):
     from oracle import binding as ob
     from tests.test_gpu_fuzz import _random_set

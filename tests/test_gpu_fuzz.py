@@ -9,6 +9,7 @@ import pytest
 from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
+_OFF = int(os.environ.get("PDL_FUZZ_OFFSET", "0"))       # another stretch of the seed space (wide runs)
 
 
 def _random_set(seed):
@@ -48,7 +49,7 @@ def _random_set(seed):
     return residues.astype(np.uint8), offsets, np.asarray(gid, np.uint32), k
 
 
-@pytest.mark.parametrize("seed", list(range(3000, 3000 + int(os.environ.get("PDL_FUZZ_SEEDS", "240")))))   # widen with PDL_FUZZ_SEEDS=N
+@pytest.mark.parametrize("seed", list(range(3000 + _OFF, 3000 + _OFF + int(os.environ.get("PDL_FUZZ_SEEDS", "240")))))   # widen with PDL_FUZZ_SEEDS=N
 def test_random_small_sets_match_the_oracle(seed):
     from oracle import binding as ob
     from pandelos_amd import _lib
@@ -79,7 +80,7 @@ def test_random_small_sets_match_the_oracle(seed):
             H.assert_scores_equal(nat_s.generate_scores_part(g).as_dict(), want[g], f"seed {seed} shard genome {g}")
 
 
-@pytest.mark.parametrize("seed", list(range(7000, 7000 + int(os.environ.get("PDL_STRESS_SETS", "6")))))   # widen with PDL_STRESS_SETS=N
+@pytest.mark.parametrize("seed", list(range(7000 + _OFF, 7000 + _OFF + int(os.environ.get("PDL_STRESS_SETS", "6")))))   # widen with PDL_STRESS_SETS=N
 def test_mid_size_sets_under_every_join_tier_match_the_oracle(seed):
     """The bugs that came and went with the timing (stale put-aside entries, barriers without an LDS wait) never showed on
     the tiny sets above: they need thousands of rows and several workgroups per CU.  Mid-size families-and-genomes sets,

@@ -109,3 +109,27 @@ def test_mid_size_sets_under_every_join_tier_match_the_oracle(seed):
         tm = nat.timings()
         assert tm["aside_reloads"] == 0 and tm["aside_repeats"] == 0, f"seed {seed} tier {tier}: the put-aside canary went off"
     nat.close()
+
+
+@pytest.mark.parametrize("seed", list(range(9000 + _OFF, 9000 + _OFF + max(2, int(os.environ.get("PDL_STRESS_SETS", "6")) // 2))))
+def test_mid_size_sets_in_genome_batches_match_the_oracle(seed):
+    """Genome batches on one dictionary (pdl_set_genome_shard after the build: head bits put back, the batch's range lists made
+    again; the build's buffers released under "low_memory" or kept), a batch size and a first tier drawn per seed."""
+    from oracle import binding as ob
+    from pandelos_amd.calculate_k import calculate_k
+    from pandelos_amd.pangene_native import PangeneNative
+    from pandelos_amd.synth import make_gene_set
+    rng = np.random.default_rng(seed)
+    gs = make_gene_set(genomes=int(rng.integers(3, 30)), genes_per_genome=int(rng.integers(60, 400)), mean_len=int(rng.integers(60, 200)),
+                       sub_rate=float(rng.choice([0.02, 0.08, 0.2])), seed=seed, protein_like=bool(rng.random() < 0.3))
+    k = max(3, calculate_k(gs.residues) - int(rng.integers(0, 2)))
+    per_batch = int(rng.integers(1, gs.genomes + 1))
+    ora = ob.Oracle(gs.residues, gs.offsets, gs.genome_of, k)
+    nat = PangeneNative.open()
+    nat.set_option("join_tier1", int(rng.choice([-1, 10, 11, 21, 0])))
+    seen = 0
+    for g, s in nat.scores_in_batches(k, gs.residues, gs.offsets, gs.genome_of, per_batch, low_memory=bool(rng.integers(0, 2))):
+        H.assert_scores_equal(s.as_dict(), ora.scores(g), f"seed {seed} batches of {per_batch} genome {g}")
+        seen += 1
+    assert seen == ora.genomes
+    nat.close()

@@ -520,3 +520,32 @@ def test_ranks_that_wrap_past_64_bits_unnoticed_match_the_oracle(letters, k):
     for g in range(ora.genomes):
         H.assert_scores_equal(lr.generate_scores_part(g).as_dict(), want[g], f"{letters} letters k={k} three ranks genome {g}")
     lr.close()
+
+
+@pytest.mark.parametrize("shape", [
+    dict(genomes=40, genes_per_genome=200, mean_len=400, sub_rate=0.05, seed=7701),      # rows of 4-9 k lookups: both forms of tier 0, some beyond
+    dict(genomes=24, genes_per_genome=150, mean_len=1200, sub_rate=0.08, seed=7702),     # genes of > 960 shared k-mers: more ranges than a cycle stages
+    dict(genomes=70, genes_per_genome=120, mean_len=250, sub_rate=0.03, seed=7703),      # close homologs in 70 genomes: rows of ~8 k lookups
+])
+def test_long_rows_go_through_both_forms_of_the_partition_tier_and_beyond(shape):
+    """Tier 0 forced on for sets whose rows do NOT fit its first form: rows that alone exceed 4096 lookups take the 512-thread
+    form, rows beyond 8192 lookups or 960 ranges are handed on to the filter tier (descriptors written by the tier that hands
+    them on), and every genome must still match the oracle."""
+    from oracle import binding as ob
+    from pandelos_amd.calculate_k import calculate_k
+    from pandelos_amd.pangene_native import PangeneNative
+    from pandelos_amd.synth import make_gene_set
+    gs = make_gene_set(**shape)
+    k = calculate_k(gs.residues)
+    ora = ob.Oracle(gs.residues, gs.offsets, gs.genome_of, k)
+    nat = PangeneNative.open()
+    nat.set_option("join_tier0", 1)
+    nat.preprocess(k, gs.residues, gs.offsets, gs.genome_of)
+    assert nat.cost.total_cost == ora.total_cost
+    for g in range(ora.genomes):
+        H.assert_scores_equal(nat.generate_scores_part(g).as_dict(), ora.scores(g), f"{shape} genome {g}")
+    tm = nat.timings()
+    assert tm["aside_reloads"] == 0
+    print(f"{shape['genomes']}x{shape['genes_per_genome']}x{shape['mean_len']}: rows {tm['scored_rows']}, to the filter tier {tm['tier1_rows']}, tier 2 {tm['tier2_rows']}, tier 3 {tm['overflow_rows']}")
+    assert 0 < tm["tier1_rows"] < tm["scored_rows"]          # some rows stayed in tier 0, some went beyond it
+    nat.close()
